@@ -1,0 +1,89 @@
+// kf_kernels.h — device-resident state and launch wrappers of the HIP KinectFusion kernels.
+#pragma once
+#include "kf_math.h"
+#include "../../include/kfusion_hip.h"
+
+namespace kf {
+
+struct Gauss5 { float g[5]; };
+
+// Parameter blocks that live in HBM and are rewritten by the control kernel, so that a whole frame
+// (19 ICP iterations included) is queued without the host ever reading the pose back.
+struct TrackParams { M4 view; int have_reference; int pad[3]; };       // view = K * inverse(raycastPose)
+struct IntegrateParams { M4 invTrack; M4 K; int enabled; int pad[3]; };
+struct RayParams { M4 view; int enabled; int pad[3]; };
+
+struct DevState {
+    M4 pose;          // camera-to-world, updated in place by k_solve
+    M4 oldPose;       // pose at tracking start (cpp/kernels.cpp:947)
+    M4 raycastPose;   // pose of the last raycast (cpp/kernels.cpp:978)
+    TrackParams track;
+    IntegrateParams integ;
+    RayParams ray;
+    RayParams render;
+    float reduction[32];   // summed row 0 of the reference's 8x32 reduction output
+    int have_reference;    // 0 until the first raycast (frames 0-3)
+    int tracked;
+    int integrated;
+    int level_done[KFH_MAX_LEVELS];
+    unsigned long long icp_iterations;
+    unsigned long long integrate_updated;   // U of SURVEY §8(d), summed over all integrate launches
+};
+
+struct FrameLogEntry { M4 pose; int tracked; int integrated; int frame; int pad; };
+
+// bits of k_control's op mask, executed in this order by one thread
+enum ControlOps {
+    OP_TRACK_BEGIN = 1,   // oldPose = pose; view = K * inverse(raycastPose); clear level flags
+    OP_TRACK_END = 2,     // checkPoseKernel -> tracked
+    OP_INTEG_BEGIN = 4,   // checkPoseKernel again, gate, invTrack = inverse(pose)
+    OP_RAY_BEGIN = 8,     // frame > 2: raycastPose = pose; view = raycastPose * invK
+    OP_FRAME_END = 16,    // append {pose, tracked, integrated} to the device frame log
+    OP_RENDER_BEGIN = 32  // render.view = viewPose * invK
+};
+
+struct ControlArgs {
+    float k[4];
+    unsigned frame, tracking_rate, integration_rate;
+    unsigned width, height;
+    float track_threshold;
+    int use_view_pose;   // OP_RENDER_BEGIN: 1 -> view_pose below, 0 -> current pose
+    M4 view_pose;
+    unsigned log_capacity;
+};
+
+namespace launch {
+unsigned track_blocks(unsigned w, unsigned h);
+void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
+void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
+                const Gauss5 &g, float e_d, hipStream_t s);
+void mm2meters(float *out, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio, hipStream_t s);
+void bilateral(float *out, const float *in, unsigned W, unsigned H, const Gauss5 &g, float e_d, hipStream_t s);
+void half_sample(float *out, const float *in, unsigned inW, unsigned inH, float e_d, hipStream_t s);
+void depth2vertex(float4 *vertex, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s);
+void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H, hipStream_t s);
+void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s);
+// fused ICP pass: per-pixel association + block partial sums.  pose/params/skip are device pointers.
+void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, const float4 *inVertex,
+                  const float4 *inNormal, unsigned inW, unsigned inH, const float4 *refVertex, const float4 *refNormal,
+                  unsigned refW, unsigned refH, const M4 *pose, const TrackParams *tp, const int *skip,
+                  float dist_threshold, float normal_threshold, hipStream_t s);
+void reduce_trackdata(float *partials, const kfh_track_data *J, unsigned JW, unsigned W, unsigned H, hipStream_t s);
+// sums the block partials in a fixed order into st->reduction (or out32) and, if do_solve, updates st->pose
+void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, int level, float icp_threshold,
+           int do_solve, hipStream_t s);
+void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s);
+void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);
+void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s);
+void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
+               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, hipStream_t s);
+void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
+             unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
+             hipStream_t s);
+void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s);
+void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
+void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
+                   const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
+                   hipStream_t s);
+}  // namespace launch
+}  // namespace kf

@@ -1,0 +1,854 @@
+// kf_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the KinectFusion hot path.
+//
+// One kernel per row of SURVEY.md §8(a); the arithmetic of each follows the reference CPP backend
+// (kfusion/src/cpp/kernels.cpp, cited as cpp:LINE, and kfusion/include/commons.h) operation by
+// operation — the file is compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt so
+// that integer outputs (TSDF, colours, result codes) match the CPU bit for bit and float outputs differ
+// only where libm does (expf in the bilateral filter) or where a sum is re-associated (ICP reduction).
+//
+// Nothing here is a dense contraction: no MFMA.  Every kernel is bound by HBM/L2 traffic or by launch
+// latency; the layout choices are about coalescing (64 consecutive x per wave), LDS-staged stencils and
+// keeping the pose on the device so the 19-iteration ICP loop never round-trips to the host.
+#include "kf_kernels.h"
+
+namespace kf {
+
+// =====================================================================================
+// initVolumeKernel  (cpp:147-157, commons.h:176-180): every voxel <- short2(32766, 0)
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_init_volume(uint32_t *__restrict__ vol, size_t n) {
+    const uint32_t v = 0x00007FFEu;  // little-endian {x = 32766, y = 0}
+    const size_t n4 = n / 4;
+    uint4 *v4 = reinterpret_cast<uint4 *>(vol);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) v4[i] = make_uint4(v, v, v, v);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) vol[i] = v;
+}
+
+// =====================================================================================
+// mm2metersKernel (cpp:562-589) and bilateralFilterKernel (cpp:159-198), fused.
+// A 32x8 block stages a 36x12 tile of metre depths in LDS (border taps clamp to the edge)
+// and each thread walks the 5x5 window from LDS.  Loop order (x offset outer, y offset inner) and
+// the running sums follow cpp:179-193 so the float result only differs from the CPU through expf.
+// =====================================================================================
+constexpr int PBX = 32, PBY = 8, PR = 2;
+
+template <bool FROM_MM>
+__global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floatDepth, float *__restrict__ out,
+                                                        const void *__restrict__ inv, unsigned W, unsigned H,
+                                                        unsigned inW, int ratio, Gauss5 g, float e_d_squared_2) {
+    __shared__ float tile[PBY + 2 * PR][PBX + 2 * PR + 1];
+    const int x0 = blockIdx.x * PBX, y0 = blockIdx.y * PBY;
+    const int tid = threadIdx.y * PBX + threadIdx.x;
+    constexpr int TW = PBX + 2 * PR, TH = PBY + 2 * PR;
+    for (int idx = tid; idx < TW * TH; idx += PBX * PBY) {
+        const int ty = idx / TW, tx = idx - ty * TW;
+        const int gx = imax(0, imin(x0 + tx - PR, (int)W - 1));
+        const int gy = imax(0, imin(y0 + ty - PR, (int)H - 1));
+        float v;
+        if (FROM_MM) v = static_cast<const uint16_t *>(inv)[gx * ratio + inW * gy * ratio] / 1000.0f;
+        else v = static_cast<const float *>(inv)[gx + gy * W];
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= (int)W || y >= (int)H) return;
+    const unsigned pos = x + y * W;
+    const float center = tile[threadIdx.y + PR][threadIdx.x + PR];
+    if (FROM_MM && floatDepth) floatDepth[pos] = center;
+    if (center == 0) { out[pos] = 0; return; }
+    float sum = 0.0f, t = 0.0f;
+#pragma unroll
+    for (int i = -PR; i <= PR; ++i) {
+#pragma unroll
+        for (int j = -PR; j <= PR; ++j) {
+            const float cur = tile[threadIdx.y + PR + j][threadIdx.x + PR + i];
+            if (cur > 0) {
+                const float mod = sq(cur - center);
+                const float factor = g.g[i + PR] * g.g[j + PR] * expf(-mod / e_d_squared_2);
+                t += factor * cur;
+                sum += factor;
+            }
+        }
+    }
+    out[pos] = t / sum;
+}
+
+__global__ __launch_bounds__(256) void k_mm2meters(float *__restrict__ out, unsigned W, unsigned H,
+                                                   const uint16_t *__restrict__ in, unsigned inW, int ratio) {
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    out[x + W * y] = in[x * ratio + inW * y * ratio] / 1000.0f;
+}
+
+// =====================================================================================
+// halfSampleRobustImageKernel (cpp:591-626), r = 1: robust mean of the 2x2 block under (2x, 2y)
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_half_sample(float *__restrict__ out, const float *__restrict__ in,
+                                                     unsigned inW, unsigned outW, unsigned outH, float e_d) {
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= outW || y >= outH) return;
+    const float2 r0 = *reinterpret_cast<const float2 *>(in + 2 * x + (size_t)(2 * y) * inW);
+    const float2 r1 = *reinterpret_cast<const float2 *>(in + 2 * x + (size_t)(2 * y + 1) * inW);
+    const float center = r0.x;
+    float sum = 0.0f, t = 0.0f;
+    // (i, j) = (0,0), (0,1), (1,0), (1,1): i is the row offset, j the column offset (cpp:607-608)
+    if (fabsf(r0.x - center) < e_d) { sum += 1.0f; t += r0.x; }
+    if (fabsf(r0.y - center) < e_d) { sum += 1.0f; t += r0.y; }
+    if (fabsf(r1.x - center) < e_d) { sum += 1.0f; t += r1.x; }
+    if (fabsf(r1.y - center) < e_d) { sum += 1.0f; t += r1.y; }
+    out[x + y * outW] = t / sum;
+}
+
+// =====================================================================================
+// depth2vertexKernel (cpp:200-218) and vertex2normalKernel (cpp:220-249)
+// =====================================================================================
+__device__ __forceinline__ f3 back_project(float d, int x, int y, const M4 &invK) {
+    return d > 0 ? scale3(rotate(invK, mk3((float)x, (float)y, 1.f)), d) : mk3(0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_depth2vertex(float4 *__restrict__ vertex, const float *__restrict__ depth,
+                                                      unsigned W, unsigned H, M4 invK) {
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const f3 v = back_project(depth[x + y * W], x, y, invK);
+    vertex[x + y * W] = make_float4(v.x, v.y, v.z, 0.f);
+}
+
+// Invalid pixels write only .x: .y/.z keep whatever the previous frame left there.
+__device__ __forceinline__ void store_normal(float4 *out, f3 left, f3 right, f3 up, f3 down) {
+    if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) {
+        reinterpret_cast<float *>(out)[0] = kInvalid;
+        return;
+    }
+    const f3 dxv = sub3(right, left), dyv = sub3(down, up);
+    const f3 n = normalize3(cross3(dyv, dxv));
+    *out = make_float4(n.x, n.y, n.z, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_vertex2normal(float4 *__restrict__ out, const float4 *__restrict__ in,
+                                                       unsigned W, unsigned H) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= (int)W || y >= (int)H) return;
+    const int xl = imax(x - 1, 0), xr = imin(x + 1, (int)W - 1), yu = imax(y - 1, 0), yd = imin(y + 1, (int)H - 1);
+    const float4 l = in[xl + W * y], r = in[xr + W * y], u = in[x + W * yu], d = in[x + W * yd];
+    store_normal(out + x + y * W, mk3(l.x, l.y, l.z), mk3(r.x, r.y, r.z), mk3(u.x, u.y, u.z), mk3(d.x, d.y, d.z));
+}
+
+// Fused form used by the pipeline: the 34x10 depth tile (1-pixel halo, clamp-to-edge) is staged in
+// LDS once; the centre vertex and its four neighbours are back-projected from it with the same
+// expression depth2vertexKernel uses, so both outputs carry the bits of the two-pass version.
+__global__ __launch_bounds__(PBX *PBY) void k_vertex_normal(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                            const float *__restrict__ depth, unsigned W, unsigned H,
+                                                            M4 invK) {
+    __shared__ float tile[PBY + 2][PBX + 2 + 1];
+    const int x0 = blockIdx.x * PBX, y0 = blockIdx.y * PBY;
+    const int tid = threadIdx.y * PBX + threadIdx.x;
+    constexpr int TW = PBX + 2, TH = PBY + 2;
+    for (int idx = tid; idx < TW * TH; idx += PBX * PBY) {
+        const int ty = idx / TW, tx = idx - ty * TW;
+        const int gx = imax(0, imin(x0 + tx - 1, (int)W - 1));
+        const int gy = imax(0, imin(y0 + ty - 1, (int)H - 1));
+        tile[ty][tx] = depth[gx + gy * W];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= (int)W || y >= (int)H) return;
+    const int tx = threadIdx.x + 1, ty = threadIdx.y + 1;
+    const int xl = imax(x - 1, 0), xr = imin(x + 1, (int)W - 1), yu = imax(y - 1, 0), yd = imin(y + 1, (int)H - 1);
+    const f3 c = back_project(tile[ty][tx], x, y, invK);
+    const f3 l = back_project(tile[ty][tx - 1], xl, y, invK);
+    const f3 r = back_project(tile[ty][tx + 1], xr, y, invK);
+    const f3 u = back_project(tile[ty - 1][tx], x, yu, invK);
+    const f3 d = back_project(tile[ty + 1][tx], x, yd, invK);
+    vertex[x + y * W] = make_float4(c.x, c.y, c.z, 0.f);
+    store_normal(normal + x + y * W, l, r, u, d);
+}
+
+// =====================================================================================
+// trackKernel (cpp:497-560) + reduceKernel (cpp:251-495), fused.
+// Each thread associates its pixels, accumulates the 32 sums of the reference layout
+//   [0] sum e^2  [1..6] sum e*J  [7..27] upper triangle of J^T J (row-major)
+//   [28] inliers [29] #(-4) [30] #(-5) [31] #(-1..-3)
+// in registers, then a wave64 shuffle tree and an LDS step produce one 32-float partial per block.
+// Partials are summed by k_solve in block order: no atomics, so the result is bitwise reproducible
+// run to run (the reference's OpenMP build is not).  The sum is re-associated with
+// respect to the serial CPU order, which is the one float difference this path has by design.
+// =====================================================================================
+constexpr int TR_THREADS = 256;
+constexpr unsigned TR_MAX_BLOCKS = 512;
+
+struct PixelTrack { int result; float error; float J[6]; };
+
+__device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, const float4 *__restrict__ inV,
+                                                  const float4 *__restrict__ inN, unsigned inW,
+                                                  const float4 *__restrict__ refV, const float4 *__restrict__ refN,
+                                                  unsigned refW, unsigned refH, const M4 &T, const M4 &view,
+                                                  int have_reference, float dist_threshold, float normal_threshold) {
+    PixelTrack r;
+    r.error = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.J[i] = 0.f;
+    const float4 n4 = inN[px + py * inW];
+    if (n4.x == kInvalid) { r.result = -1; return r; }
+    const float4 v4 = inV[px + py * inW];
+    const f3 pv = xform(T, mk3(v4.x, v4.y, v4.z));
+    unsigned rx = 0, ry = 0;
+    if (have_reference) {
+        const f3 pp = xform(view, pv);
+        const float u = pp.x / pp.z + 0.5f, w = pp.y / pp.z + 0.5f;
+        if (u < 0 || u > refW - 1 || w < 0 || w > refH - 1) { r.result = -2; return r; }
+        rx = (unsigned)u; ry = (unsigned)w;
+    }
+    const float4 rn4 = refN[rx + ry * refW];
+    if (rn4.x == kInvalid) { r.result = -3; return r; }
+    const float4 rv4 = refV[rx + ry * refW];
+    const f3 n_ref = mk3(rn4.x, rn4.y, rn4.z);
+    const f3 diff = sub3(mk3(rv4.x, rv4.y, rv4.z), pv);
+    const f3 pn = rotate(T, mk3(n4.x, n4.y, n4.z));
+    if (length3(diff) > dist_threshold) { r.result = -4; return r; }
+    if (dot3(pn, n_ref) < normal_threshold) { r.result = -5; return r; }
+    r.result = 1;
+    r.error = dot3(n_ref, diff);
+    r.J[0] = n_ref.x; r.J[1] = n_ref.y; r.J[2] = n_ref.z;
+    const f3 c = cross3(pv, n_ref);
+    r.J[3] = c.x; r.J[4] = c.y; r.J[5] = c.z;
+    return r;
+}
+
+__device__ __forceinline__ void accumulate(float (&acc)[32], int result, float e, const float (&J)[6]) {
+    if (result < 1) {
+        acc[29] += result == -4 ? 1.f : 0.f;
+        acc[30] += result == -5 ? 1.f : 0.f;
+        acc[31] += result > -4 ? 1.f : 0.f;
+        return;
+    }
+    acc[0] += e * e;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[1 + i] += e * J[i];
+    int k = 7;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) acc[k++] += J[r] * J[c];
+    acc[28] += 1.f;
+}
+
+// 256 threads -> one 32-float partial.  Fixed tree: wave64 shuffle, then waves 0..3 in order.
+__device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__restrict__ partial) {
+    __shared__ float sm[TR_THREADS / 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sm[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v = sm[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < TR_THREADS / 64; ++w) v += sm[w][threadIdx.x];
+        partial[threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void k_track_reduce(
+    float *__restrict__ partials, int *__restrict__ result_map, kfh_track_data *__restrict__ track_out,
+    const float4 *__restrict__ inV, const float4 *__restrict__ inN, unsigned inW, unsigned inH,
+    const float4 *__restrict__ refV, const float4 *__restrict__ refN, unsigned refW, unsigned refH,
+    const M4 *__restrict__ posep, const TrackParams *__restrict__ tp, const int *__restrict__ skip,
+    float dist_threshold, float normal_threshold) {
+    if (skip && *skip) return;
+    const M4 T = *posep;
+    const M4 view = tp->view;
+    const int have_reference = tp->have_reference;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    const unsigned n = inW * inH;
+    for (unsigned p = blockIdx.x * TR_THREADS + threadIdx.x; p < n; p += gridDim.x * TR_THREADS) {
+        const unsigned py = p / inW, px = p - py * inW;
+        const PixelTrack r = track_pixel(px, py, inV, inN, inW, refV, refN, refW, refH, T, view, have_reference,
+                                         dist_threshold, normal_threshold);
+        // output rows keep the full-resolution stride on every level (cpp:512)
+        if (result_map) result_map[px + py * refW] = r.result;
+        if (track_out) {
+            kfh_track_data *o = track_out + px + py * refW;
+            o->result = r.result;
+            if (r.result == 1) {   // error / J are only defined for inliers
+                o->error = r.error;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) o->J[i] = r.J[i];
+            }
+        }
+        accumulate(acc, r.result, r.error, r.J);
+    }
+    if (partials) block_reduce_store(acc, partials + (size_t)blockIdx.x * 32);
+}
+
+// reduceKernel on an existing TrackData map (kernel-level API; the pipeline uses the fused kernel)
+__global__ __launch_bounds__(TR_THREADS) void k_reduce_trackdata(float *__restrict__ partials,
+                                                                 const kfh_track_data *__restrict__ J, unsigned JW,
+                                                                 unsigned W, unsigned H) {
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    const unsigned n = W * H;
+    for (unsigned p = blockIdx.x * TR_THREADS + threadIdx.x; p < n; p += gridDim.x * TR_THREADS) {
+        const unsigned py = p / W, px = p - py * W;
+        const kfh_track_data row = J[px + py * JW];
+        accumulate(acc, row.result, row.error, row.J);
+    }
+    block_reduce_store(acc, partials + (size_t)blockIdx.x * 32);
+}
+
+// =====================================================================================
+// Partial sums -> reduction row 0, then updatePoseKernel (cpp:759-775) on the device:
+//   x = pinv(J^T J) J^T e (double), pose <- exp(x) * pose (float), level done when |x| < icp_threshold.
+// One block; the pose never leaves HBM between ICP iterations.
+// =====================================================================================
+__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold) {
+    double x[6];
+    solve6(red + 1, x);
+    const M4 delta = se3_exp_to_m4(x);
+    pose = matmul(delta, pose);
+    double n2 = 0.0;
+    for (int i = 0; i < 6; ++i) n2 += x[i] * x[i];
+    return sqrt(n2) < icp_threshold;
+}
+
+__global__ __launch_bounds__(256) void k_solve(DevState *__restrict__ st, float *__restrict__ out32,
+                                               const float *__restrict__ partials, unsigned nblocks, int level,
+                                               float icp_threshold, int do_solve) {
+    if (st && do_solve && st->level_done[level]) return;
+    __shared__ float sm[8][32];
+    __shared__ float red[32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    float acc = 0.f;
+    for (unsigned b = g; b < nblocks; b += 8) acc += partials[(size_t)b * 32 + c];
+    sm[g][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v = sm[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += sm[k][threadIdx.x];
+        red[threadIdx.x] = v;
+        if (out32) out32[threadIdx.x] = v;
+        if (st) st->reduction[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && st && do_solve) {
+        M4 pose = st->pose;
+        const bool converged = apply_update(pose, red, icp_threshold);
+        st->pose = pose;
+        st->icp_iterations += 1;
+        if (converged) st->level_done[level] = 1;
+    }
+}
+
+__global__ void k_update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    M4 p = *pose;
+    float red[32];
+    for (int i = 0; i < 32; ++i) red[i] = reduction32[i];
+    const bool c = apply_update(p, red, icp_threshold);
+    *pose = p;
+    *converged = c ? 1 : 0;
+}
+
+// checkPoseKernel (cpp:777-792)
+__device__ __forceinline__ bool check_pose_dev(M4 &pose, const M4 &oldPose, const float *red, unsigned W, unsigned H,
+                                               float track_threshold) {
+    if (((double)sqrtf(red[0] / red[28]) > 2e-2) || (red[28] / (W * H) < track_threshold)) {
+        pose = oldPose;
+        return false;
+    }
+    return true;
+}
+
+__global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr,
+                             int *ok) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    M4 p = *pose;
+    const M4 o = *oldPose;
+    float red[32];
+    for (int i = 0; i < 32; ++i) red[i] = reduction32[i];
+    *ok = check_pose_dev(p, o, red, W, H, thr) ? 1 : 0;
+    *pose = p;
+}
+
+// =====================================================================================
+// Control kernel: the scalar glue of Kfusion::tracking / integration / raycasting (cpp:924-1004) run by one
+// thread on the device, so frame gating and pose algebra need no host round trip.
+// =====================================================================================
+__global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, ControlArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool track_frame = (a.frame % a.tracking_rate) == 0;   // cpp:927
+    if (ops & OP_TRACK_BEGIN) {
+        for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
+        if (track_frame) {
+            st->oldPose = st->pose;                                  // cpp:947
+            st->track.have_reference = st->have_reference;
+            if (st->have_reference)                                  // cpp:948
+                st->track.view = matmul(camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]), inverse(st->raycastPose));
+        }
+    }
+    if (ops & OP_TRACK_END) {
+        if (track_frame) {                                           // cpp:968-969
+            M4 p = st->pose;
+            const bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
+            st->pose = p;
+            st->tracked = ok ? 1 : 0;
+        } else {
+            st->tracked = 0;
+        }
+    }
+    if (ops & OP_INTEG_BEGIN) {                                      // cpp:991-1000
+        M4 p = st->pose;
+        const bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
+        st->pose = p;
+        const bool go = (ok && (a.frame % a.integration_rate) == 0) || (a.frame <= 3);
+        st->integ.enabled = go ? 1 : 0;
+        st->integrated = go ? 1 : 0;
+        if (go) {
+            st->integ.invTrack = inverse(p);
+            st->integ.K = camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
+        }
+    }
+    if (ops & OP_RAY_BEGIN) {                                        // cpp:977-982
+        if (a.frame > 2) {
+            st->raycastPose = st->pose;
+            st->have_reference = 1;
+            st->ray.view = matmul(st->raycastPose, inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]));
+            st->ray.enabled = 1;
+        } else {
+            st->ray.enabled = 0;
+        }
+    }
+    if (ops & OP_FRAME_END) {
+        if (log && a.log_capacity) {
+            FrameLogEntry &e = log[a.frame % a.log_capacity];
+            e.pose = st->pose; e.tracked = st->tracked; e.integrated = st->integrated; e.frame = (int)a.frame; e.pad = 0;
+        }
+    }
+    if (ops & OP_RENDER_BEGIN) {                                     // cpp:1035-1036
+        const M4 vp = a.use_view_pose ? a.view_pose : st->pose;
+        st->render.view = matmul(vp, inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]));
+        st->render.enabled = 1;
+    }
+}
+
+// =====================================================================================
+// integrateKernel (cpp:628-673).  A wave owns 64 consecutive x of one (y, z-chunk): every voxel access is
+// a full 256-byte line of the x-fastest short2 grid.  The camera-space position is carried along z by
+// repeated addition exactly like the CPU loop (cpp:645-646); a thread that starts at z0 > 0 first replays
+// the z0 additions in registers so that its float state carries the bits of the serial march.
+// Voxels are read only when all four tests pass: algorithmic traffic is 8*U + 4*P bytes.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
+                                                   f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
+                                                   const IntegrateParams *__restrict__ ip, float mu, float maxweight,
+                                                   unsigned zchunk, unsigned long long *__restrict__ updated_total) {
+    if (!ip->enabled) return;
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    unsigned updated = 0;
+    if (x < sx && y < sy) {
+    const M4 invTrack = ip->invTrack, K = ip->K;
+    const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
+    const f3 cameraDelta = rotate(K, delta);
+    f3 pos = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
+    f3 cam = xform(K, pos);
+    const unsigned z0 = blockIdx.z * zchunk;
+    const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
+    for (unsigned z = 0; z < z0; ++z) { pos = add3(pos, delta); cam = add3(cam, cameraDelta); }
+    const size_t plane = (size_t)sx * sy;
+    short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    for (unsigned z = z0; z < z1; ++z, pos = add3(pos, delta), cam = add3(cam, cameraDelta), cell += plane) {
+        if (pos.z < 0.0001f) continue;
+        const float px = cam.x / cam.z + 0.5f, py = cam.y / cam.z + 0.5f;
+        if (px < 0 || px > wm1 || py < 0 || py > hm1) continue;
+        const unsigned ux = (unsigned)px, uy = (unsigned)py;
+        const float d = depth[ux + uy * W];
+        if (d == 0) continue;
+        const float diff = (d - cam.z) * sqrtf(1 + sq(pos.x / pos.z) + sq(pos.y / pos.z));
+        if (diff > -mu) {
+            const float sdf = fmin_h(1.f, diff / mu);
+            const short2 c = *cell;
+            float tsdf = c.x * kShort2Float, w = c.y;
+            tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
+            w = fmin_h(w + 1, maxweight);
+            *cell = make_short2((short)(tsdf * 32766.0f), (short)w);
+            ++updated;
+        }
+    }
+    }
+    // instrumentation (U = voxels that passed all four tests): one atomic per wave
+    if (updated_total) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) updated += __shfl_down(updated, off, 64);
+        if ((threadIdx.x & 63) == 0 && updated) atomicAdd(updated_total, (unsigned long long)updated);
+    }
+}
+
+// =====================================================================================
+// Volume sampling (commons.h:191-301) and the ray march (cpp:674-725)
+// =====================================================================================
+struct VolView {
+    const short2 *data;
+    int sx, sy, sz;
+    f3 dim;
+    size_t plane;
+};
+
+__device__ __forceinline__ float tap(const VolView &v, int x, int y, int z) {
+    return (float)v.data[(size_t)x + (size_t)y * v.sx + (size_t)z * v.plane].x;   // commons.h:172-174
+}
+
+struct Taps { int lo[3], up[3]; f3 fr; int base[3]; };
+
+__device__ __forceinline__ Taps locate(const VolView &v, f3 pos) {
+    Taps t;
+    const float sp0 = (pos.x * v.sx / v.dim.x) - 0.5f, sp1 = (pos.y * v.sy / v.dim.y) - 0.5f,
+                sp2 = (pos.z * v.sz / v.dim.z) - 0.5f;
+    const float f0 = floorf(sp0), f1 = floorf(sp1), f2 = floorf(sp2);
+    t.base[0] = (int)f0; t.base[1] = (int)f1; t.base[2] = (int)f2;
+    t.fr = mk3(sp0 - f0, sp1 - f1, sp2 - f2);
+    const int s[3] = {v.sx, v.sy, v.sz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // lower = max(base, 0), upper = min(base + 1, size - 1) (commons.h:198-200); the outer clamps only
+        // act where the reference would index out of bounds
+        t.lo[a] = imin(imax(t.base[a], 0), s[a] - 1);
+        t.up[a] = imax(imin(t.base[a] + 1, s[a] - 1), 0);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float interp(const VolView &v, f3 pos) {
+    const Taps t = locate(v, pos);
+    const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
+    return (((tap(v, t.lo[0], t.lo[1], t.lo[2]) * (1 - fx) + tap(v, t.up[0], t.lo[1], t.lo[2]) * fx) * (1 - fy)
+             + (tap(v, t.lo[0], t.up[1], t.lo[2]) * (1 - fx) + tap(v, t.up[0], t.up[1], t.lo[2]) * fx) * fy) * (1 - fz)
+            + ((tap(v, t.lo[0], t.lo[1], t.up[2]) * (1 - fx) + tap(v, t.up[0], t.lo[1], t.up[2]) * fx) * (1 - fy)
+               + (tap(v, t.lo[0], t.up[1], t.up[2]) * (1 - fx) + tap(v, t.up[0], t.up[1], t.up[2]) * fx) * fy) * fz)
+           * kShort2Float;
+}
+
+// Central differences blended trilinearly (commons.h:215-301).  For axis A the four planes are
+// ll = max(base-1,0), lo = max(base,0), up = min(base+1,size-1), uu = min(base+2,size-1); the low
+// difference is v(up)-v(ll) and the high one v(uu)-v(lo).
+__device__ __forceinline__ f3 grad(const VolView &v, f3 pos) {
+    const Taps t = locate(v, pos);
+    const int s[3] = {v.sx, v.sy, v.sz};
+    int ll[3], uu[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ll[a] = imin(imax(t.base[a] - 1, 0), s[a] - 1);
+        uu[a] = imax(imin(t.base[a] + 2, s[a] - 1), 0);
+    }
+    const int *lo = t.lo, *up = t.up;
+    const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
+    f3 g;
+    g.x = (((tap(v, up[0], lo[1], lo[2]) - tap(v, ll[0], lo[1], lo[2])) * (1 - fx)
+            + (tap(v, uu[0], lo[1], lo[2]) - tap(v, lo[0], lo[1], lo[2])) * fx) * (1 - fy)
+           + ((tap(v, up[0], up[1], lo[2]) - tap(v, ll[0], up[1], lo[2])) * (1 - fx)
+              + (tap(v, uu[0], up[1], lo[2]) - tap(v, lo[0], up[1], lo[2])) * fx) * fy) * (1 - fz)
+          + (((tap(v, up[0], lo[1], up[2]) - tap(v, ll[0], lo[1], up[2])) * (1 - fx)
+              + (tap(v, uu[0], lo[1], up[2]) - tap(v, lo[0], lo[1], up[2])) * fx) * (1 - fy)
+             + ((tap(v, up[0], up[1], up[2]) - tap(v, ll[0], up[1], up[2])) * (1 - fx)
+                + (tap(v, uu[0], up[1], up[2]) - tap(v, lo[0], up[1], up[2])) * fx) * fy) * fz;
+    g.y = (((tap(v, lo[0], up[1], lo[2]) - tap(v, lo[0], ll[1], lo[2])) * (1 - fx)
+            + (tap(v, up[0], up[1], lo[2]) - tap(v, up[0], ll[1], lo[2])) * fx) * (1 - fy)
+           + ((tap(v, lo[0], uu[1], lo[2]) - tap(v, lo[0], lo[1], lo[2])) * (1 - fx)
+              + (tap(v, up[0], uu[1], lo[2]) - tap(v, up[0], lo[1], lo[2])) * fx) * fy) * (1 - fz)
+          + (((tap(v, lo[0], up[1], up[2]) - tap(v, lo[0], ll[1], up[2])) * (1 - fx)
+              + (tap(v, up[0], up[1], up[2]) - tap(v, up[0], ll[1], up[2])) * fx) * (1 - fy)
+             + ((tap(v, lo[0], uu[1], up[2]) - tap(v, lo[0], lo[1], up[2])) * (1 - fx)
+                + (tap(v, up[0], uu[1], up[2]) - tap(v, up[0], lo[1], up[2])) * fx) * fy) * fz;
+    g.z = (((tap(v, lo[0], lo[1], up[2]) - tap(v, lo[0], lo[1], ll[2])) * (1 - fx)
+            + (tap(v, up[0], lo[1], up[2]) - tap(v, up[0], lo[1], ll[2])) * fx) * (1 - fy)
+           + ((tap(v, lo[0], up[1], up[2]) - tap(v, lo[0], up[1], ll[2])) * (1 - fx)
+              + (tap(v, up[0], up[1], up[2]) - tap(v, up[0], up[1], ll[2])) * fx) * fy) * (1 - fz)
+          + (((tap(v, lo[0], lo[1], uu[2]) - tap(v, lo[0], lo[1], lo[2])) * (1 - fx)
+              + (tap(v, up[0], lo[1], uu[2]) - tap(v, up[0], lo[1], lo[2])) * fx) * (1 - fy)
+             + ((tap(v, lo[0], up[1], uu[2]) - tap(v, lo[0], up[1], lo[2])) * (1 - fx)
+                + (tap(v, up[0], up[1], uu[2]) - tap(v, up[0], up[1], lo[2])) * fx) * fy) * fz;
+    const f3 cell = mk3(v.dim.x / v.sx, v.dim.y / v.sy, v.dim.z / v.sz);
+    return scale3(mul3(g, cell), 0.5f * kShort2Float);
+}
+
+__device__ __forceinline__ float4 cast_ray(const VolView &v, unsigned px, unsigned py, const M4 &view, float nearPlane,
+                                           float farPlane, float step, float largestep) {
+    const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
+    const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
+    const f3 invR = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const f3 tbot = mul3(scale3(invR, -1.0f), origin);
+    const f3 ttop = mul3(invR, sub3(v.dim, origin));
+    const f3 tmin = mk3(fmin_h(ttop.x, tbot.x), fmin_h(ttop.y, tbot.y), fmin_h(ttop.z, tbot.z));
+    const f3 tmax = mk3(fmax_h(ttop.x, tbot.x), fmax_h(ttop.y, tbot.y), fmax_h(ttop.z, tbot.z));
+    const float largest_tmin = fmax_h(fmax_h(tmin.x, tmin.y), fmax_h(tmin.x, tmin.z));
+    const float smallest_tmax = fmin_h(fmin_h(tmax.x, tmax.y), fmin_h(tmax.x, tmax.z));
+    const float tnear = fmax_h(largest_tmin, nearPlane);
+    const float tfar = fmin_h(smallest_tmax, farPlane);
+    if (tnear < tfar) {
+        float t = tnear, stepsize = largestep;
+        float f_t = interp(v, add3(origin, scale3(dir, t)));
+        float f_tt = 0;
+        if (f_t > 0) {
+            for (; t < tfar; t += stepsize) {
+                f_tt = interp(v, add3(origin, scale3(dir, t)));
+                if (f_tt < 0) break;
+                if (f_tt < 0.8f) stepsize = step;
+                f_t = f_tt;
+            }
+            if (f_tt < 0) {
+                t = t + stepsize * f_tt / (f_t - f_tt);
+                const f3 p = add3(origin, scale3(dir, t));
+                return make_float4(p.x, p.y, p.z, t);
+            }
+        }
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Pixel mapping shared by raycast and renderVolume: a 256-thread block covers 16x16 pixels, each wave an
+// 8x8 screen tile, so the 64 rays of a wave walk neighbouring voxels (gather locality in L1/L2).
+__device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// raycastKernel (cpp:726-757)
+__global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal, unsigned W,
+                                                 unsigned H, const short2 *__restrict__ vol, unsigned sx, unsigned sy,
+                                                 unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
+                                                 float farPlane, float step, float largestep) {
+    if (!rp->enabled) return;
+    unsigned x, y;
+    tile_pixel(x, y);
+    if (x >= W || y >= H) return;
+    const M4 view = rp->view;
+    VolView v;
+    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
+    const float4 hit = cast_ray(v, x, y, view, nearPlane, farPlane, step, largestep);
+    const unsigned p = x + y * W;
+    if (hit.w > 0.0) {
+        vertex[p] = make_float4(hit.x, hit.y, hit.z, 0.f);
+        const f3 n = grad(v, mk3(hit.x, hit.y, hit.z));
+        if (length3(n) == 0) {
+            reinterpret_cast<float *>(normal + p)[0] = kInvalid;
+        } else {
+            const f3 nn = normalize3(n);
+            normal[p] = make_float4(nn.x, nn.y, nn.z, 0.f);
+        }
+    } else {
+        vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        normal[p] = make_float4(kInvalid, 0.f, 0.f, 0.f);
+    }
+}
+
+// renderVolumeKernel (cpp:880-913)
+__global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
+                                                       const short2 *__restrict__ vol, unsigned sx, unsigned sy,
+                                                       unsigned sz, f3 dim, const RayParams *__restrict__ rp,
+                                                       float nearPlane, float farPlane, float step, float largestep,
+                                                       f3 light, f3 ambient) {
+    unsigned x, y;
+    tile_pixel(x, y);
+    if (x >= W || y >= H) return;
+    const M4 view = rp->view;
+    VolView v;
+    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
+    const float4 hit = cast_ray(v, x, y, view, nearPlane, farPlane, step, largestep);
+    uchar4 o = make_uchar4(0, 0, 0, 0);
+    if (hit.w > 0) {
+        const f3 test = mk3(hit.x, hit.y, hit.z);
+        const f3 n = grad(v, test);
+        if (length3(n) > 0) {
+            const f3 diff = normalize3(sub3(light, test));
+            const float dir = fmax_h(dot3(normalize3(n), diff), 0.f);
+            const f3 col = scale3(mk3(clamp_h(dir + ambient.x, 0.f, 1.f), clamp_h(dir + ambient.y, 0.f, 1.f),
+                                      clamp_h(dir + ambient.z, 0.f, 1.f)), 255);
+            o = make_uchar4((unsigned char)col.x, (unsigned char)col.y, (unsigned char)col.z, 0);
+        }
+    }
+    out[x + y * W] = o;
+}
+
+// renderDepthKernel (cpp:814-842) with the double-precision ramp of commons.h:86-147
+__device__ __forceinline__ uchar4 gs2rgb(double h) {
+    double r = 0, g = 0, b = 0;
+    const double v = 0.75, m = 0.25, sv = 0.6667;
+    h *= 6.0;
+    const int sextant = (int)h;
+    const double fract = h - sextant;
+    const double vsf = v * sv * fract, mid1 = m + vsf, mid2 = v - vsf;
+    switch (sextant) {
+    case 0: r = v; g = mid1; b = m; break;
+    case 1: r = mid2; g = v; b = m; break;
+    case 2: r = m; g = v; b = mid1; break;
+    case 3: r = m; g = mid2; b = v; break;
+    case 4: r = mid1; g = m; b = v; break;
+    case 5: r = v; g = m; b = mid2; break;
+    default: break;
+    }
+    return make_uchar4((unsigned char)(r * 255), (unsigned char)(g * 255), (unsigned char)(b * 255), 0);
+}
+
+__global__ __launch_bounds__(256) void k_render_depth(uchar4 *__restrict__ out, const float *__restrict__ depth,
+                                                      unsigned W, unsigned H, float nearPlane, float farPlane) {
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float rangeScale = 1 / (farPlane - nearPlane);
+    const unsigned p = y * W + x;
+    const float d = depth[p];
+    uchar4 o;
+    if (d < nearPlane) o = make_uchar4(255, 255, 255, 0);
+    else if (d > farPlane) o = make_uchar4(0, 0, 0, 0);
+    else o = gs2rgb((d - nearPlane) * rangeScale);
+    out[p] = o;
+}
+
+// renderTrackKernel (cpp:844-878) on the int32 result map the fused ICP pass keeps
+__global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, const int *__restrict__ result,
+                                                      unsigned W, unsigned H) {
+    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    uchar4 o;
+    switch (result[x + y * W]) {
+    case 1: o = make_uchar4(128, 128, 128, 0); break;
+    case -1: o = make_uchar4(0, 0, 0, 0); break;
+    case -2: o = make_uchar4(255, 0, 0, 0); break;
+    case -3: o = make_uchar4(0, 255, 0, 0); break;
+    case -4: o = make_uchar4(0, 0, 255, 0); break;
+    case -5: o = make_uchar4(255, 255, 0, 0); break;
+    default: o = make_uchar4(255, 128, 128, 0); break;
+    }
+    out[x + y * W] = o;
+}
+
+// =====================================================================================
+// launch wrappers
+// =====================================================================================
+namespace launch {
+
+static inline dim3 grid_rows(unsigned W, unsigned H) { return dim3((W + 63) / 64, (H + 3) / 4); }
+static inline dim3 block_rows() { return dim3(64, 4); }
+
+unsigned track_blocks(unsigned w, unsigned h) {
+    const unsigned n = (w * h + TR_THREADS - 1) / TR_THREADS;
+    return n < 1 ? 1 : (n > TR_MAX_BLOCKS ? TR_MAX_BLOCKS : n);
+}
+
+void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
+    const size_t n = (size_t)sx * sy * sz;
+    k_init_volume<<<2048, 256, 0, s>>>(reinterpret_cast<uint32_t *>(vol), n);
+}
+
+void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
+                const Gauss5 &g, float e_d, hipStream_t s) {
+    const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
+    k_bilateral<true><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, e_d * e_d * 2);
+}
+
+void mm2meters(float *out, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio, hipStream_t s) {
+    k_mm2meters<<<grid_rows(W, H), block_rows(), 0, s>>>(out, W, H, in, inW, ratio);
+}
+
+void bilateral(float *out, const float *in, unsigned W, unsigned H, const Gauss5 &g, float e_d, hipStream_t s) {
+    const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
+    k_bilateral<false><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, e_d * e_d * 2);
+}
+
+void half_sample(float *out, const float *in, unsigned inW, unsigned inH, float e_d, hipStream_t s) {
+    const unsigned outW = inW / 2, outH = inH / 2;
+    k_half_sample<<<grid_rows(outW, outH), block_rows(), 0, s>>>(out, in, inW, outW, outH, e_d);
+}
+
+void depth2vertex(float4 *vertex, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s) {
+    k_depth2vertex<<<grid_rows(W, H), block_rows(), 0, s>>>(vertex, depth, W, H, invK);
+}
+
+void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H, hipStream_t s) {
+    k_vertex2normal<<<grid_rows(W, H), block_rows(), 0, s>>>(normal, vertex, W, H);
+}
+
+void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s) {
+    const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
+    k_vertex_normal<<<grid, block, 0, s>>>(vertex, normal, depth, W, H, invK);
+}
+
+void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, const float4 *inVertex,
+                  const float4 *inNormal, unsigned inW, unsigned inH, const float4 *refVertex, const float4 *refNormal,
+                  unsigned refW, unsigned refH, const M4 *pose, const TrackParams *tp, const int *skip,
+                  float dist_threshold, float normal_threshold, hipStream_t s) {
+    k_track_reduce<<<track_blocks(inW, inH), TR_THREADS, 0, s>>>(partials, result_map, track_out, inVertex, inNormal, inW,
+                                                               inH, refVertex, refNormal, refW, refH, pose, tp, skip,
+                                                               dist_threshold, normal_threshold);
+}
+
+void reduce_trackdata(float *partials, const kfh_track_data *J, unsigned JW, unsigned W, unsigned H, hipStream_t s) {
+    k_reduce_trackdata<<<track_blocks(W, H), TR_THREADS, 0, s>>>(partials, J, JW, W, H);
+}
+
+void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, int level, float icp_threshold,
+           int do_solve, hipStream_t s) {
+    k_solve<<<1, 256, 0, s>>>(st, out32, partials, nblocks, level, icp_threshold, do_solve);
+}
+
+void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s) {
+    k_control<<<1, 64, 0, s>>>(st, log, ops, a);
+}
+
+void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s) {
+    k_update_pose<<<1, 64, 0, s>>>(pose, reduction32, icp_threshold, converged);
+}
+
+void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s) {
+    k_check_pose<<<1, 64, 0, s>>>(pose, oldPose, reduction32, W, H, thr, ok);
+}
+
+void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
+               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, hipStream_t s) {
+    // enough z-chunks to put >= ~4096 waves in flight on 256 CUs; each chunk replays z0 additions
+    const unsigned waves_xy = ((sx + 63) / 64) * sy;
+    unsigned nchunks = (4096 + waves_xy - 1) / waves_xy;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 8) nchunks = 8;
+    if (nchunks > sz) nchunks = sz;
+    const unsigned zchunk = (sz + nchunks - 1) / nchunks;
+    const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
+    k_integrate<<<grid, block_rows(), 0, s>>>(reinterpret_cast<short2 *>(vol), sx, sy, sz, dim, depth, W, H, p, mu,
+                                               maxweight, zchunk, updated_total);
+}
+
+void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
+             unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
+             hipStream_t s) {
+    const dim3 grid((W + 15) / 16, (H + 15) / 16);
+    k_raycast<<<grid, 256, 0, s>>>(vertex, normal, W, H, reinterpret_cast<const short2 *>(vol), sx, sy, sz, dim, p,
+                                   nearPlane, farPlane, step, largestep);
+}
+
+void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {
+    k_render_depth<<<grid_rows(W, H), block_rows(), 0, s>>>(out, depth, W, H, nearPlane, farPlane);
+}
+
+void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s) {
+    k_render_track<<<grid_rows(W, H), block_rows(), 0, s>>>(out, result_map, W, H);
+}
+
+void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
+                   const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
+                   hipStream_t s) {
+    const dim3 grid((W + 15) / 16, (H + 15) / 16);
+    k_render_volume<<<grid, 256, 0, s>>>(out, W, H, reinterpret_cast<const short2 *>(vol), sx, sy, sz, dim, p, nearPlane,
+                                         farPlane, step, largestep, light, ambient);
+}
+
+}  // namespace launch
+}  // namespace kf

@@ -1,0 +1,230 @@
+// kf_math.h — small-vector and pose algebra for the HIP backend (host + device).
+//
+// Arithmetic follows the reference CPP backend operation by operation so that, built with
+// -ffp-contract=off and correctly rounded fp32 divide/sqrt, the device produces the same bits as
+// the host code it replaces: kfusion/thirdparty/cutil_math.h (host branch: fminf/fmaxf are plain
+// ternaries, rsqrtf = 1/sqrtf, dot sums left to right) and kfusion/include/commons.h:317-412.
+// The pose algebra stands where the reference calls TooN (gaussian_elimination, SE3::exp,
+// GR_SVD::backsub) — restated from TooN's published sources, since TooN is not vendored.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KF_HD __host__ __device__ __forceinline__
+
+namespace kf {
+
+struct f3 { float x, y, z; };
+struct M4 { float m[4][4]; };
+
+constexpr float kInvalid = -2.0f;                     // KFUSION_INVALID
+constexpr float kShort2Float = 0.00003051944088f;     // commons.h:162
+
+KF_HD float fmin_h(float a, float b) { return a < b ? a : b; }   // cutil_math.h:43-45
+KF_HD float fmax_h(float a, float b) { return a > b ? a : b; }   // cutil_math.h:47-49
+KF_HD float clamp_h(float f, float a, float b) { return fmax_h(a, fmin_h(f, b)); }
+KF_HD int imin(int a, int b) { return a < b ? a : b; }
+KF_HD int imax(int a, int b) { return a > b ? a : b; }
+KF_HD float sq(float r) { return r * r; }
+
+KF_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+KF_HD f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+KF_HD f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+KF_HD f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+KF_HD f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+KF_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+KF_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+KF_HD float length3(f3 v) { return sqrtf(dot3(v, v)); }
+KF_HD f3 normalize3(f3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return scale3(v, inv); }
+
+// commons.h:331-341
+KF_HD f3 xform(const M4 &M, f3 v) {
+    return mk3(dot3(mk3(M.m[0][0], M.m[0][1], M.m[0][2]), v) + M.m[0][3],
+               dot3(mk3(M.m[1][0], M.m[1][1], M.m[1][2]), v) + M.m[1][3],
+               dot3(mk3(M.m[2][0], M.m[2][1], M.m[2][2]), v) + M.m[2][3]);
+}
+KF_HD f3 rotate(const M4 &M, f3 v) {
+    return mk3(dot3(mk3(M.m[0][0], M.m[0][1], M.m[0][2]), v), dot3(mk3(M.m[1][0], M.m[1][1], M.m[1][2]), v),
+               dot3(mk3(M.m[2][0], M.m[2][1], M.m[2][2]), v));
+}
+
+KF_HD M4 zero4() { M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = 0.0f; return r; }
+KF_HD M4 identity4() { M4 r = zero4(); for (int i = 0; i < 4; ++i) r.m[i][i] = 1.0f; return r; }
+// commons.h:343-359
+KF_HD M4 camera_matrix(float fx, float fy, float cx, float cy) {
+    M4 K = zero4();
+    K.m[0][0] = fx; K.m[0][2] = cx; K.m[1][1] = fy; K.m[1][2] = cy; K.m[2][2] = 1.0f; K.m[3][3] = 1.0f;
+    return K;
+}
+KF_HD M4 inverse_camera_matrix(float fx, float fy, float cx, float cy) {
+    M4 K = zero4();
+    K.m[0][0] = 1.0f / fx; K.m[0][2] = -cx / fx; K.m[1][1] = 1.0f / fy; K.m[1][2] = -cy / fy;
+    K.m[2][2] = 1.0f; K.m[3][3] = 1.0f;
+    return K;
+}
+
+// commons.h:373-378
+KF_HD M4 matmul(const M4 &A, const M4 &B) {
+    M4 R;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc += A.m[r][k] * B.m[k][c];
+            R.m[r][c] = acc;
+        }
+    return R;
+}
+
+// commons.h:365-371: Gauss elimination with partial pivoting against the identity (float storage,
+// row multiplier held in double as TooN does), then back substitution.
+KF_HD M4 inverse(const M4 &Ain) {
+    float A[4][4], B[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { A[i][j] = Ain.m[i][j]; B[i][j] = (i == j) ? 1.0f : 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int piv = i;
+        float best = fabsf(A[i][i]);
+#pragma unroll
+        for (int r = i + 1; r < 4; ++r) {
+            const double v = fabsf(A[r][i]);
+            if (v > best) { best = (float)v; piv = r; }
+        }
+        // row swap written branch-free over a fixed index range so the arrays stay in registers
+#pragma unroll
+        for (int r = i + 1; r < 4; ++r) {
+            if (r == piv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= i) { const float t = A[i][j]; A[i][j] = A[r][j]; A[r][j] = t; }
+                    const float u = B[i][j]; B[i][j] = B[r][j]; B[r][j] = u;
+                }
+            }
+        }
+        const float inv_pivot = 1.0f / A[i][i];
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) A[i][j] *= inv_pivot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) B[i][j] *= inv_pivot;
+#pragma unroll
+        for (int u = i + 1; u < 4; ++u) {
+            const double factor = A[u][i];
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) A[u][j] = (float)(A[u][j] - factor * A[i][j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) B[u][j] = (float)(B[u][j] - factor * B[i][j]);
+        }
+    }
+    M4 X;
+#pragma unroll
+    for (int i = 3; i >= 0; --i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = B[i][c];
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) v -= A[i][j] * X.m[j][c];
+            X.m[i][c] = v;
+        }
+    return X;
+}
+
+// TooN SE3<double>::exp + rodrigues_so3_exp, materialised as a float 4x4 (commons.h:406-412).
+KF_HD M4 se3_exp_to_m4(const double mu[6]) {
+    const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+    const double v0 = mu[0], v1 = mu[1], v2 = mu[2], w0 = mu[3], w1 = mu[4], w2 = mu[5];
+    const double theta_sq = w0 * w0 + w1 * w1 + w2 * w2;
+    const double theta = sqrt(theta_sq);
+    const double c0 = w1 * v2 - w2 * v1, c1 = w2 * v0 - w0 * v2, c2 = w0 * v1 - w1 * v0;
+    double A, B, t0, t1, t2;
+    if (theta_sq < 1e-8) {
+        A = 1.0 - one_6th * theta_sq;
+        B = 0.5;
+        t0 = v0 + 0.5 * c0; t1 = v1 + 0.5 * c1; t2 = v2 + 0.5 * c2;
+    } else {
+        double C;
+        if (theta_sq < 1e-6) {
+            C = one_6th * (1.0 - one_20th * theta_sq);
+            A = 1.0 - theta_sq * C;
+            B = 0.5 - 0.25 * one_6th * theta_sq;
+        } else {
+            const double inv_theta = 1.0 / theta;
+            A = sin(theta) * inv_theta;
+            B = (1 - cos(theta)) * (inv_theta * inv_theta);
+            C = (1 - A) * (inv_theta * inv_theta);
+        }
+        const double d0 = w1 * c2 - w2 * c1, d1 = w2 * c0 - w0 * c2, d2 = w0 * c1 - w1 * c0;
+        t0 = v0 + B * c0 + C * d0; t1 = v1 + B * c1 + C * d1; t2 = v2 + B * c2 + C * d2;
+    }
+    M4 out;
+    {
+        const double wx2 = w0 * w0, wy2 = w1 * w1, wz2 = w2 * w2;
+        out.m[0][0] = (float)(1.0 - B * (wy2 + wz2));
+        out.m[1][1] = (float)(1.0 - B * (wx2 + wz2));
+        out.m[2][2] = (float)(1.0 - B * (wx2 + wy2));
+    }
+    { const double a = A * w2, b = B * (w0 * w1); out.m[0][1] = (float)(b - a); out.m[1][0] = (float)(b + a); }
+    { const double a = A * w1, b = B * (w0 * w2); out.m[0][2] = (float)(b + a); out.m[2][0] = (float)(b - a); }
+    { const double a = A * w0, b = B * (w1 * w2); out.m[1][2] = (float)(b - a); out.m[2][1] = (float)(b + a); }
+    out.m[0][3] = (float)t0; out.m[1][3] = (float)t1; out.m[2][3] = (float)t2;
+    out.m[3][0] = 0.0f; out.m[3][1] = 0.0f; out.m[3][2] = 0.0f; out.m[3][3] = 1.0f;
+    return out;
+}
+
+// commons.h:380-404: x = pinv(C) b with singular values below max/1e6 dropped; C symmetric 6x6
+// (21 upper-triangle floats, row-major) so the SVD is the eigendecomposition.  Cyclic Jacobi, double.
+// vals = {b[6], C upper triangle[21]}.
+__host__ __device__ inline void solve6(const float *vals, double x[6]) {
+    double C[6][6], Q[6][6], b[6];
+    for (int i = 0; i < 6; ++i) b[i] = vals[i];
+    {
+        int p = 6;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) { C[r][c] = vals[p]; C[c][r] = vals[p]; ++p; }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) Q[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            diag += C[i][i] * C[i][i];
+            for (int j = i + 1; j < 6; ++j) off += C[i][j] * C[i][j];
+        }
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int i = 0; i < 5; ++i)
+            for (int j = i + 1; j < 6; ++j) {
+                const double apq = C[i][j];
+                if (apq == 0.0) continue;
+                const double theta = (C[j][j] - C[i][i]) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 6; ++k) {
+                    const double cki = C[k][i], ckj = C[k][j];
+                    C[k][i] = cs * cki - sn * ckj;
+                    C[k][j] = sn * cki + cs * ckj;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double cik = C[i][k], cjk = C[j][k];
+                    C[i][k] = cs * cik - sn * cjk;
+                    C[j][k] = sn * cik + cs * cjk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double qki = Q[k][i], qkj = Q[k][j];
+                    Q[k][i] = cs * qki - sn * qkj;
+                    Q[k][j] = sn * qki + cs * qkj;
+                }
+            }
+    }
+    double smax = 0.0;
+    for (int i = 0; i < 6; ++i) smax = fabs(C[i][i]) > smax ? fabs(C[i][i]) : smax;
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        const double l = C[i][i];
+        if (!(fabs(l) * 1e6 > smax)) continue;
+        double qb = 0.0;
+        for (int k = 0; k < 6; ++k) qb += Q[k][i] * b[k];
+        const double coef = qb / l;
+        for (int k = 0; k < 6; ++k) x[k] += coef * Q[k][i];
+    }
+}
+
+}  // namespace kf

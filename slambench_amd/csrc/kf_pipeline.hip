@@ -1,0 +1,783 @@
+// kf_pipeline.hip — the Kfusion backend object behind the C ABI of include/kfusion_hip.h.
+//
+// Mirrors the pipeline methods of the reference CPP backend (kfusion/src/cpp/kernels.cpp:67-137,
+// 915-1055) with per-instance state instead of file-scope globals (cpp:39-57), so several contexts
+// (one per GPU, or several per GPU) can live in one process.  All per-frame work is queued on one HIP
+// stream; the pose, the frame gating flags and the ICP normal equations stay in HBM (DevState) and
+// the host only reads them back when the caller asks for a verdict or the pose.
+#include "kf_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace kf;
+
+// constant_parameters.h:15-26
+static const float e_delta = 0.1f;
+static const int radius = 2;
+static const float dist_threshold = 0.1f;
+static const float normal_threshold = 0.8f;
+static const float track_threshold = 0.15f;
+static const float maxweight = 100.0f;
+static const float nearPlane = 0.4f;
+static const float farPlane = 4.0f;
+static const float delta_gauss = 4.0f;
+
+static thread_local std::string g_last_error;
+
+static bool hip_ok(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess) return true;
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+    fprintf(stderr, "[kfusion-hip] %s\n", buf);
+    return false;
+}
+#define HIP_TRY(x) hip_ok((x), #x, __FILE__, __LINE__)
+
+struct PendingCopy { void *dst; const void *src; size_t bytes; };
+
+struct kfh_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    unsigned W = 0, H = 0;
+    unsigned volRes[3] = {0, 0, 0};
+    f3 volDim = {0, 0, 0};
+    float initPose[3] = {0, 0, 0};
+    std::vector<int> iterations;
+    float step = 0.f;
+    Gauss5 gauss;
+    // device buffers (cpp:39-55)
+    uint16_t *d_input = nullptr; size_t input_capacity = 0;
+    float *d_floatDepth = nullptr;
+    std::vector<float *> d_scaled;
+    std::vector<float4 *> d_inV, d_inN;
+    float4 *d_vertex = nullptr, *d_normal = nullptr;
+    int *d_result = nullptr;
+    float *d_partials = nullptr;
+    int16_t *d_volume = nullptr;
+    DevState *d_state = nullptr;
+    FrameLogEntry *d_log = nullptr;
+    unsigned log_capacity = 8192;
+    uchar4 *d_render[3] = {nullptr, nullptr, nullptr};
+    // pinned host staging
+    uint16_t *h_input[2] = {nullptr, nullptr};
+    hipEvent_t input_done[2] = {nullptr, nullptr};
+    int input_slot = 0;
+    DevState *h_state = nullptr;
+    uchar4 *h_render[3] = {nullptr, nullptr, nullptr};
+    std::vector<PendingCopy> pending;
+    // optional HIP-event timing of pipeline phases (kfh_set_profiling)
+    unsigned prof_mask = 0;
+    std::vector<hipEvent_t> prof_events[KFH_PROF_COUNT];   // start/stop pairs, in issue order
+    size_t prof_used[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
+    double prof_ms[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t prof_n[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
+    // host mirror
+    bool mirror_stale = false;
+    M4 viewPose; bool useViewPose = false;
+};
+
+static hipEvent_t prof_event(kfh_context *c, int phase) {
+    std::vector<hipEvent_t> &v = c->prof_events[phase];
+    if (c->prof_used[phase] == v.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        v.push_back(e);
+    }
+    return v[c->prof_used[phase]++];
+}
+static void prof_collect(kfh_context *c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int p = 0; p < KFH_PROF_COUNT; ++p) {
+        for (size_t i = 0; i + 1 < c->prof_used[p]; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->prof_events[p][i], c->prof_events[p][i + 1]) == hipSuccess) {
+                c->prof_ms[p] += ms;
+                c->prof_n[p] += 1;
+            }
+        }
+        c->prof_used[p] = 0;
+    }
+}
+static inline void prof_begin(kfh_context *c, int phase) {
+    if (!(c->prof_mask & (1u << phase))) return;
+    if (c->prof_used[phase] >= 16384) prof_collect(c);
+    HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
+}
+static inline void prof_end(kfh_context *c, int phase) {
+    if (!(c->prof_mask & (1u << phase))) return;
+    HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
+}
+
+static void fill_control(const kfh_context *c, ControlArgs &a, const float k[4], unsigned frame, unsigned tracking_rate,
+                         unsigned integration_rate) {
+    std::memset(&a, 0, sizeof a);
+    if (k) for (int i = 0; i < 4; ++i) a.k[i] = k[i];
+    a.frame = frame;
+    a.tracking_rate = tracking_rate ? tracking_rate : 1;
+    a.integration_rate = integration_rate ? integration_rate : 1;
+    a.width = c->W; a.height = c->H;
+    a.track_threshold = track_threshold;
+    a.use_view_pose = c->useViewPose ? 1 : 0;
+    a.view_pose = c->viewPose;
+    a.log_capacity = c->log_capacity;
+}
+
+static void refresh_mirror(kfh_context *c) {
+    if (!c->mirror_stale) return;
+    HIP_TRY(hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->mirror_stale = false;
+}
+
+static void flush_pending(kfh_context *c) {
+    for (const PendingCopy &p : c->pending) std::memcpy(p.dst, p.src, p.bytes);
+    c->pending.clear();
+}
+
+static inline unsigned level_dim(unsigned v, int l) { return v / (unsigned)(int)pow(2, l); }   // cpp:933-934
+
+// ------------------------------------------------------------------ queueing of the four phases
+static int enqueue_preprocess(kfh_context *c, const uint16_t *d_in, unsigned inW, unsigned inH) {
+    // ratio checks of mm2metersKernel (cpp:566-577)
+    if (inW < c->W || inH < c->H) return KFH_ERR_INVALID_RATIO;
+    if (inW % c->W != 0 || inH % c->H != 0) return KFH_ERR_INVALID_RATIO;
+    if (inW / c->W != inH / c->H) return KFH_ERR_INVALID_RATIO;
+    prof_begin(c, KFH_PROF_PREPROCESS);
+    launch::preprocess(c->d_floatDepth, c->d_scaled[0], c->W, c->H, d_in, inW, (int)(inW / c->W), c->gauss, e_delta,
+                       c->stream);
+    prof_end(c, KFH_PROF_PREPROCESS);
+    return 1;
+}
+
+static void enqueue_tracking(kfh_context *c, const float k[4], float icp_threshold, unsigned tracking_rate, unsigned frame) {
+    ControlArgs a;
+    fill_control(c, a, k, frame, tracking_rate, 1);
+    if (frame % a.tracking_rate != 0) {   // cpp:927-928: nothing runs, not even the pyramid
+        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
+        return;
+    }
+    const int L = (int)c->iterations.size();
+    prof_begin(c, KFH_PROF_PYRAMID);
+    for (int i = 1; i < L; ++i)   // cpp:931-935
+        launch::half_sample(c->d_scaled[i], c->d_scaled[i - 1], level_dim(c->W, i - 1), level_dim(c->H, i - 1),
+                            e_delta * 3, c->stream);
+    unsigned lw = c->W, lh = c->H;
+    for (int i = 0; i < L; ++i) {   // cpp:938-945
+        const float s = float(1 << i);
+        const M4 invK = inverse_camera_matrix(k[0] / s, k[1] / s, k[2] / s, k[3] / s);
+        launch::vertex_normal(c->d_inV[i], c->d_inN[i], c->d_scaled[i], lw, lh, invK, c->stream);
+        lw /= 2; lh /= 2;
+    }
+    prof_end(c, KFH_PROF_PYRAMID);
+    prof_begin(c, KFH_PROF_ICP);
+    launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
+    for (int level = L - 1; level >= 0; --level) {   // cpp:950-967
+        const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
+        const unsigned nb = launch::track_blocks(w, h);
+        for (int i = 0; i < c->iterations[level]; ++i) {
+            launch::track_reduce(c->d_partials, c->d_result, nullptr, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex,
+                                 c->d_normal, c->W, c->H, &c->d_state->pose, &c->d_state->track,
+                                 &c->d_state->level_done[level], dist_threshold, normal_threshold, c->stream);
+            launch::solve(c->d_state, nullptr, c->d_partials, nb, level, icp_threshold, 1, c->stream);
+        }
+    }
+    prof_end(c, KFH_PROF_ICP);
+}
+
+static void enqueue_integrate(kfh_context *c, float mu) {
+    prof_begin(c, KFH_PROF_INTEGRATE);
+    launch::integrate(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim, c->d_floatDepth, c->W, c->H,
+                      &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->stream);
+    prof_end(c, KFH_PROF_INTEGRATE);
+}
+
+static void enqueue_raycast(kfh_context *c, float mu) {
+    prof_begin(c, KFH_PROF_RAYCAST);
+    launch::raycast(c->d_vertex, c->d_normal, c->W, c->H, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
+                    &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->stream);
+    prof_end(c, KFH_PROF_RAYCAST);
+}
+
+static const uint16_t *stage_input(kfh_context *c, const uint16_t *host, unsigned inW, unsigned inH) {
+    const size_t bytes = (size_t)inW * inH * sizeof(uint16_t);
+    if (bytes > c->input_capacity) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_input) HIP_TRY(hipFree(c->d_input));
+        for (int i = 0; i < 2; ++i) if (c->h_input[i]) { HIP_TRY(hipHostFree(c->h_input[i])); c->h_input[i] = nullptr; }
+        if (!HIP_TRY(hipMalloc(&c->d_input, bytes))) return nullptr;
+        for (int i = 0; i < 2; ++i) if (!HIP_TRY(hipHostMalloc(&c->h_input[i], bytes, hipHostMallocDefault))) return nullptr;
+        c->input_capacity = bytes;
+    }
+    const int slot = c->input_slot;
+    c->input_slot ^= 1;
+    HIP_TRY(hipEventSynchronize(c->input_done[slot]));   // the copy that last used this staging slot has left it
+    std::memcpy(c->h_input[slot], host, bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input[slot], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->input_done[slot], c->stream));
+    return c->d_input;
+}
+
+static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_t res[3], const float dims[3],
+                                  const M4 &pose, const float initPose3[3], const int32_t *pyramid, int32_t n_levels,
+                                  int32_t device, void *stream) {
+    if (!width || !height || !res || !dims || !pyramid || n_levels < 1 || n_levels > KFH_MAX_LEVELS) {
+        g_last_error = "kfh_create: bad argument";
+        return nullptr;
+    }
+    if (device >= 0 && !HIP_TRY(hipSetDevice(device))) return nullptr;
+    kfh_context *c = new kfh_context();
+    HIP_TRY(hipGetDevice(&c->device));
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { if (!HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking))) { delete c; return nullptr; } c->own_stream = true; }
+    c->W = width; c->H = height;
+    for (int i = 0; i < 3; ++i) { c->volRes[i] = res[i]; c->initPose[i] = initPose3[i]; }
+    c->volDim = mk3(dims[0], dims[1], dims[2]);
+    c->iterations.assign(pyramid, pyramid + n_levels);
+    // kernels.h:117
+    const float mind = fmin_h(dims[0], fmin_h(dims[1], dims[2]));
+    unsigned maxr = res[0] > res[1] ? res[0] : res[1];
+    maxr = maxr > res[2] ? maxr : res[2];
+    c->step = mind / maxr;
+    // cpp:100-108 — the taps are computed on the host with libm expf, exactly as the reference does
+    for (int i = 0; i < 2 * radius + 1; ++i) {
+        const int x = i - 2;
+        c->gauss.g[i] = expf(-(x * x) / (2 * delta_gauss * delta_gauss));
+    }
+    bool ok = true;
+    const size_t P = (size_t)width * height;
+    ok &= HIP_TRY(hipMalloc(&c->d_floatDepth, P * sizeof(float)));
+    c->d_scaled.resize(n_levels); c->d_inV.resize(n_levels); c->d_inN.resize(n_levels);
+    for (int i = 0; i < n_levels; ++i) {
+        const size_t n = P / (size_t)(int)pow(2, i);   // cpp:80-88 (same over-allocation)
+        ok &= HIP_TRY(hipMalloc(&c->d_scaled[i], n * sizeof(float)));
+        ok &= HIP_TRY(hipMalloc(&c->d_inV[i], n * sizeof(float4)));
+        ok &= HIP_TRY(hipMalloc(&c->d_inN[i], n * sizeof(float4)));
+        if (ok) {   // calloc semantics of the reference (stale-field behaviour)
+            HIP_TRY(hipMemsetAsync(c->d_scaled[i], 0, n * sizeof(float), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_inV[i], 0, n * sizeof(float4), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_inN[i], 0, n * sizeof(float4), c->stream));
+        }
+    }
+    ok &= HIP_TRY(hipMalloc(&c->d_vertex, P * sizeof(float4)));
+    ok &= HIP_TRY(hipMalloc(&c->d_normal, P * sizeof(float4)));
+    ok &= HIP_TRY(hipMalloc(&c->d_result, P * sizeof(int)));
+    ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)launch::track_blocks(width, height) * 32 * sizeof(float)));
+    ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
+    ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
+    ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
+    for (int i = 0; i < 3; ++i) {
+        ok &= HIP_TRY(hipMalloc(&c->d_render[i], P * sizeof(uchar4)));
+        ok &= HIP_TRY(hipHostMalloc(&c->h_render[i], P * sizeof(uchar4), hipHostMallocDefault));
+    }
+    ok &= HIP_TRY(hipHostMalloc(&c->h_state, sizeof(DevState), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) ok &= HIP_TRY(hipEventCreateWithFlags(&c->input_done[i], hipEventDisableTiming));
+    if (!ok) { kfh_destroy(c); return nullptr; }
+    HIP_TRY(hipMemsetAsync(c->d_floatDepth, 0, P * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_vertex, 0, P * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_normal, 0, P * sizeof(float4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_result, 0, P * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_log, 0, (size_t)c->log_capacity * sizeof(FrameLogEntry), c->stream));
+    std::memset(c->h_state, 0, sizeof(DevState));
+    c->h_state->pose = pose;
+    HIP_TRY(hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    c->viewPose = pose;
+    kfh_reset(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return c;
+}
+
+extern "C" {
+
+int kfh_init(void) { int n = 0; return HIP_TRY(hipGetDeviceCount(&n)) && n > 0 ? KFH_OK : KFH_ERR_HIP; }
+void kfh_clean(void) {}
+int kfh_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+const char *kfh_last_error(void) { return g_last_error.c_str(); }
+const char *kfh_version(void) { return "kfusion-hip 0.1 (gfx950)"; }
+
+kfh_context *kfh_create(uint32_t width, uint32_t height, const uint32_t volume_resolution[3],
+                        const float volume_dimensions[3], const float init_pose[3], const int32_t *pyramid,
+                        int32_t n_levels, int32_t device, void *stream) {
+    if (!init_pose) { g_last_error = "kfh_create: bad argument"; return nullptr; }
+    // kernels.h:106-109: SE3<float>(x, y, z, 0, 0, 0) = identity rotation, that translation
+    M4 pose = identity4();
+    for (int i = 0; i < 3; ++i) pose.m[i][3] = init_pose[i];
+    return create_common(width, height, volume_resolution, volume_dimensions, pose, init_pose, pyramid, n_levels, device, stream);
+}
+
+kfh_context *kfh_create_with_pose(uint32_t width, uint32_t height, const uint32_t volume_resolution[3],
+                                  const float volume_dimensions[3], const float init_pose16[16], const int32_t *pyramid,
+                                  int32_t n_levels, int32_t device, void *stream) {
+    if (!init_pose16) { g_last_error = "kfh_create_with_pose: bad argument"; return nullptr; }
+    M4 pose;
+    std::memcpy(&pose, init_pose16, sizeof pose);
+    // kernels.h:124: _initPose = getPosition() is evaluated before pose is assigned in the reference; the
+    // useful meaning (position of the initial pose) is kept here
+    const float ip[3] = {pose.m[0][3], pose.m[1][3], pose.m[2][3]};
+    return create_common(width, height, volume_resolution, volume_dimensions, pose, ip, pyramid, n_levels, device, stream);
+}
+
+void kfh_destroy(kfh_context *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    flush_pending(c);
+    hipFree(c->d_input); hipFree(c->d_floatDepth);
+    for (float *p : c->d_scaled) hipFree(p);
+    for (float4 *p : c->d_inV) hipFree(p);
+    for (float4 *p : c->d_inN) hipFree(p);
+    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_volume);
+    hipFree(c->d_state); hipFree(c->d_log);
+    for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
+    for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
+    if (c->h_state) hipHostFree(c->h_state);
+    for (int p = 0; p < KFH_PROF_COUNT; ++p) for (hipEvent_t e : c->prof_events[p]) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void kfh_reset(kfh_context *c) {
+    launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
+}
+
+void kfh_synchronise(kfh_context *c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    flush_pending(c);
+}
+
+int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) {
+    if (!c || !host_depth_mm) return KFH_ERR_ARGUMENT;
+    if (in_width < c->W || in_height < c->H || in_width % c->W || in_height % c->H || in_width / c->W != in_height / c->H) {
+        fprintf(stderr, "Invalid ratio.\n");
+        return KFH_ERR_INVALID_RATIO;
+    }
+    const uint16_t *d = stage_input(c, host_depth_mm, in_width, in_height);
+    if (!d) return KFH_ERR_HIP;
+    return enqueue_preprocess(c, d, in_width, in_height);
+}
+
+int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height) {
+    if (!c || !device_depth_mm) return KFH_ERR_ARGUMENT;
+    const int r = enqueue_preprocess(c, device_depth_mm, in_width, in_height);
+    if (r == KFH_ERR_INVALID_RATIO) fprintf(stderr, "Invalid ratio.\n");
+    return r;
+}
+
+int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame) {
+    if (!c || !k || !tracking_rate) return KFH_ERR_ARGUMENT;
+    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame);
+    ControlArgs a;
+    fill_control(c, a, k, frame, tracking_rate, 1);
+    launch::control(c->d_state, c->d_log, OP_TRACK_END, a, c->stream);
+    c->mirror_stale = true;
+    refresh_mirror(c);
+    return c->h_state->tracked;
+}
+
+int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate, float mu, uint32_t frame) {
+    if (!c || !k || !integration_rate) return KFH_ERR_ARGUMENT;
+    ControlArgs a;
+    fill_control(c, a, k, frame, 1, integration_rate);
+    launch::control(c->d_state, c->d_log, OP_INTEG_BEGIN, a, c->stream);
+    enqueue_integrate(c, mu);
+    c->mirror_stale = true;
+    refresh_mirror(c);
+    return c->h_state->integrated;
+}
+
+int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
+    if (!c || !k) return KFH_ERR_ARGUMENT;
+    ControlArgs a;
+    fill_control(c, a, k, frame, 1, 1);
+    launch::control(c->d_state, c->d_log, OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
+    enqueue_raycast(c, mu);
+    return 0;   // cpp:975,984: the reference always returns false
+}
+
+int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is_device, uint32_t in_width,
+                      uint32_t in_height, const float k[4], uint32_t integration_rate, uint32_t tracking_rate,
+                      float icp_threshold, float mu, uint32_t frame) {
+    if (!c || !depth_mm || !k || !integration_rate || !tracking_rate) return KFH_ERR_ARGUMENT;
+    int r;
+    if (depth_is_device) r = kfh_preprocessing_device(c, depth_mm, in_width, in_height);
+    else r = kfh_preprocessing(c, depth_mm, in_width, in_height);
+    if (r < 0) return r;
+    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame);
+    ControlArgs a;
+    fill_control(c, a, k, frame, tracking_rate, integration_rate);
+    launch::control(c->d_state, c->d_log, OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
+    enqueue_integrate(c, mu);
+    enqueue_raycast(c, mu);
+    c->mirror_stale = true;
+    return KFH_OK;
+}
+
+static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, uint32_t h) {
+    const size_t bytes = (size_t)w * h * sizeof(uchar4);
+    HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+    for (PendingCopy &p : c->pending) if (p.dst == out) { p.src = c->h_render[slot]; p.bytes = bytes; return; }
+    PendingCopy p = {out, c->h_render[slot], bytes};
+    c->pending.push_back(p);
+}
+
+void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
+    if (!c || !out || w != c->W || h != c->H) return;
+    launch::render_depth(c->d_render[0], c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
+    queue_readback(c, 0, out, w, h);
+}
+
+void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
+    if (!c || !out || w != c->W || h != c->H) return;
+    launch::render_track(c->d_render[1], c->d_result, w, h, c->stream);
+    queue_readback(c, 1, out, w, h);
+}
+
+void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, int32_t rate, const float k[4],
+                       float largestep) {
+    if (!c || !out || !k || w != c->W || h != c->H || rate == 0) return;
+    if (frame % rate != 0) return;   // cpp:1034
+    ControlArgs a;
+    fill_control(c, a, k, (unsigned)frame, 1, 1);
+    launch::control(c->d_state, c->d_log, OP_RENDER_BEGIN, a, c->stream);
+    const f3 light = mk3(1, 1, -1.0), ambient = mk3((float)0.1, (float)0.1, (float)0.1);   // constant_parameters.h:25-26
+    launch::render_volume(c->d_render[2], w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
+                          &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient, c->stream);
+    queue_readback(c, 2, out, w, h);
+}
+
+int kfh_dump_volume(kfh_context *c, const char *filename) {
+    if (!c) return KFH_ERR_ARGUMENT;
+    if (!filename) return KFH_OK;   // cpp:1010-1012
+    printf("Dumping the volumetric representation on file: %s\n", filename);
+    const size_t n = (size_t)c->volRes[0] * c->volRes[1] * c->volRes[2];
+    std::vector<int16_t> host(n * 2);
+    if (!HIP_TRY(hipMemcpyAsync(host.data(), c->d_volume, n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream))) return KFH_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FILE *f = fopen(filename, "wb");
+    if (!f) { printf("Error opening file: %s\n", filename); return KFH_ERR_IO; }
+    std::vector<int16_t> tsdf(n);
+    for (size_t i = 0; i < n; ++i) tsdf[i] = host[2 * i];   // cpp:1022-1026: x component only
+    const size_t wr = fwrite(tsdf.data(), sizeof(int16_t), n, f);
+    fclose(f);
+    return wr == n ? KFH_OK : KFH_ERR_IO;
+}
+
+void kfh_get_pose(kfh_context *c, float out16[16]) { refresh_mirror(c); std::memcpy(out16, &c->h_state->pose, sizeof(M4)); }
+
+void kfh_set_pose(kfh_context *c, const float in16[16]) {
+    refresh_mirror(c);
+    std::memcpy(&c->h_state->pose, in16, sizeof(M4));
+    HIP_TRY(hipMemcpyAsync(&c->d_state->pose, &c->h_state->pose, sizeof(M4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+}
+
+void kfh_get_position(kfh_context *c, float out3[3]) {   // kernels.h:147-154
+    refresh_mirror(c);
+    for (int i = 0; i < 3; ++i) out3[i] = c->h_state->pose.m[i][3] - c->initPose[i];
+}
+int kfh_get_tracked(kfh_context *c) { refresh_mirror(c); return c->h_state->tracked; }
+int kfh_get_integrated(kfh_context *c) { refresh_mirror(c); return c->h_state->integrated; }
+void kfh_set_view_pose(kfh_context *c, const float *vp) {   // kernels.h:179-184
+    if (vp) { std::memcpy(&c->viewPose, vp, sizeof(M4)); c->useViewPose = true; }
+    else c->useViewPose = false;
+}
+void kfh_get_model_dimensions(kfh_context *c, float o[3]) { o[0] = c->volDim.x; o[1] = c->volDim.y; o[2] = c->volDim.z; }
+void kfh_get_model_resolution(kfh_context *c, uint32_t o[3]) { for (int i = 0; i < 3; ++i) o[i] = c->volRes[i]; }
+void kfh_get_computation_resolution(kfh_context *c, uint32_t o[2]) { o[0] = c->W; o[1] = c->H; }
+
+int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracked, int32_t *integrated) {
+    if (!c || n > c->log_capacity) return KFH_ERR_ARGUMENT;
+    std::vector<FrameLogEntry> host(n);
+    if (n) {
+        if (!HIP_TRY(hipMemcpyAsync(host.data(), c->d_log, n * sizeof(FrameLogEntry), hipMemcpyDeviceToHost, c->stream))) return KFH_ERR_HIP;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (poses) std::memcpy(poses + 16 * i, &host[i].pose, sizeof(M4));
+        if (tracked) tracked[i] = host[i].tracked;
+        if (integrated) integrated[i] = host[i].integrated;
+    }
+    return KFH_OK;
+}
+
+uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
+
+void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
+    prof_collect(c);
+    c->prof_mask = phase_mask;
+    for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; }
+}
+
+int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]) {
+    if (!c) return KFH_ERR_ARGUMENT;
+    prof_collect(c);
+    for (int p = 0; p < KFH_PROF_COUNT; ++p) { if (ms_out) ms_out[p] = c->prof_ms[p]; if (launches_out) launches_out[p] = c->prof_n[p]; }
+    return KFH_OK;
+}
+
+uint64_t kfh_icp_iterations(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->icp_iterations; }
+
+// ------------------------------------------------------------------ buffer access for parity checks
+static bool find_buffer(kfh_context *c, const std::string &n, void **ptr, size_t *bytes) {
+    const size_t P = (size_t)c->W * c->H;
+    auto set = [&](void *p, size_t b) { *ptr = p; *bytes = b; return true; };
+    if (n == "floatDepth") return set(c->d_floatDepth, P * 4);
+    if (n == "vertex") return set(c->d_vertex, P * 16);
+    if (n == "normal") return set(c->d_normal, P * 16);
+    if (n == "trackResult") return set(c->d_result, P * 4);
+    if (n == "reduction") return set(c->d_state->reduction, 32 * 4);
+    if (n == "volume") return set(c->d_volume, (size_t)c->volRes[0] * c->volRes[1] * c->volRes[2] * 4);
+    if (n == "pose") return set(&c->d_state->pose, sizeof(M4));
+    if (n == "oldPose") return set(&c->d_state->oldPose, sizeof(M4));
+    if (n == "raycastPose") return set(&c->d_state->raycastPose, sizeof(M4));
+    if (n == "state") return set(c->d_state, sizeof(DevState));
+    for (size_t l = 0; l < c->iterations.size(); ++l) {
+        const std::string s = std::to_string(l);
+        const size_t pl = (size_t)level_dim(c->W, (int)l) * level_dim(c->H, (int)l);
+        if (n == "scaledDepth" + s) return set(c->d_scaled[l], pl * 4);
+        if (n == "inputVertex" + s) return set(c->d_inV[l], pl * 16);
+        if (n == "inputNormal" + s) return set(c->d_inN[l], pl * 16);
+    }
+    return false;
+}
+
+int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64_t capacity) {
+    void *p; size_t b;
+    if (!c || !name || !find_buffer(c, name, &p, &b)) return KFH_ERR_ARGUMENT;
+    if (!host_out) return (int64_t)b;
+    if (capacity < b) return KFH_ERR_ARGUMENT;
+    if (!HIP_TRY(hipMemcpyAsync(host_out, p, b, hipMemcpyDeviceToHost, c->stream))) return KFH_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return (int64_t)b;
+}
+
+int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, uint64_t nbytes) {
+    void *p; size_t b;
+    if (!c || !name || !host_in || !find_buffer(c, name, &p, &b) || nbytes != b) return KFH_ERR_ARGUMENT;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!HIP_TRY(hipMemcpy(p, host_in, b, hipMemcpyHostToDevice))) return KFH_ERR_HIP;
+    c->mirror_stale = true;
+    return (int64_t)b;
+}
+
+void *kfh_device_pointer(kfh_context *c, const char *name) {
+    void *p; size_t b;
+    if (!c || !name || !find_buffer(c, name, &p, &b)) return nullptr;
+    return p;
+}
+
+// ------------------------------------------------------------------ kernel-level entry points
+// Parameter blocks the kernels read from HBM are uploaded into a small per-process scratch area.
+struct Scratch {
+    std::mutex mu;
+    void *dev = nullptr;
+    size_t cap = 0;
+    int device = -1;
+};
+static Scratch g_scratch;
+
+static void *scratch(size_t bytes, hipStream_t s) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    HIP_TRY(hipStreamSynchronize(s));
+    if (g_scratch.device != dev || g_scratch.cap < bytes) {
+        if (g_scratch.dev && g_scratch.device == dev) hipFree(g_scratch.dev);
+        const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+        if (!HIP_TRY(hipMalloc(&g_scratch.dev, cap))) return nullptr;
+        g_scratch.cap = cap;
+        g_scratch.device = dev;
+    }
+    return g_scratch.dev;
+}
+
+static M4 load16(const float *p) { M4 m; std::memcpy(&m, p, sizeof m); return m; }
+static Gauss5 load_gauss(const float *g5) { Gauss5 g; for (int i = 0; i < 5; ++i) g.g[i] = g5[i]; return g; }
+
+void kfh_k_init_volume(int16_t *vol, const uint32_t size[3], void *stream) {
+    launch::init_volume(vol, size[0], size[1], size[2], (hipStream_t)stream);
+}
+
+static int ratio_of(uint32_t out_w, uint32_t out_h, uint32_t in_w, uint32_t in_h) {
+    if (!out_w || !out_h) return -1;
+    if (in_w < out_w || in_h < out_h) return -1;
+    if (in_w % out_w != 0 || in_h % out_h != 0) return -1;
+    if (in_w / out_w != in_h / out_h) return -1;
+    return (int)(in_w / out_w);
+}
+
+int kfh_k_mm2meters(float *out, uint32_t out_w, uint32_t out_h, const uint16_t *in, uint32_t in_w, uint32_t in_h, void *stream) {
+    const int r = ratio_of(out_w, out_h, in_w, in_h);
+    if (r < 0) return KFH_ERR_INVALID_RATIO;
+    launch::mm2meters(out, out_w, out_h, in, in_w, r, (hipStream_t)stream);
+    return KFH_OK;
+}
+
+void kfh_k_bilateral_filter(float *out, const float *in, uint32_t w, uint32_t h, const float *g5, float e_d, int32_t r, void *stream) {
+    if (r != radius) { g_last_error = "bilateral radius must be 2"; return; }
+    launch::bilateral(out, in, w, h, load_gauss(g5), e_d, (hipStream_t)stream);
+}
+
+int kfh_k_preprocess(float *float_depth, float *filtered, uint32_t w, uint32_t h, const uint16_t *in, uint32_t in_w, uint32_t in_h,
+                     const float *g5, float e_d, void *stream) {
+    const int r = ratio_of(w, h, in_w, in_h);
+    if (r < 0) return KFH_ERR_INVALID_RATIO;
+    launch::preprocess(float_depth, filtered, w, h, in, in_w, r, load_gauss(g5), e_d, (hipStream_t)stream);
+    return KFH_OK;
+}
+
+void kfh_k_half_sample(float *out, const float *in, uint32_t in_w, uint32_t in_h, float e_d, int32_t r, void *stream) {
+    if (r != 1) { g_last_error = "half sample radius must be 1"; return; }
+    launch::half_sample(out, in, in_w, in_h, e_d, (hipStream_t)stream);
+}
+
+void kfh_k_depth2vertex(float *vertex4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) {
+    launch::depth2vertex(reinterpret_cast<float4 *>(vertex4), depth, w, h, load16(invK16), (hipStream_t)stream);
+}
+
+void kfh_k_vertex2normal(float *normal4, const float *vertex4, uint32_t w, uint32_t h, void *stream) {
+    launch::vertex2normal(reinterpret_cast<float4 *>(normal4), reinterpret_cast<const float4 *>(vertex4), w, h, (hipStream_t)stream);
+}
+
+void kfh_k_vertex_normal(float *vertex4, float *normal4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) {
+    launch::vertex_normal(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), depth, w, h, load16(invK16), (hipStream_t)stream);
+}
+
+struct TrackScratch { M4 pose; TrackParams tp; float partials[512 * 32]; };
+
+static void track_common(float *out32, int32_t *result_map, kfh_track_data *track_out, const float *in_vertex4,
+                         const float *in_normal4, uint32_t in_w, uint32_t in_h, const float *ref_vertex4,
+                         const float *ref_normal4, uint32_t ref_w, uint32_t ref_h, const float T16[16], const float view16[16],
+                         float dist_thr, float normal_thr, int32_t have_reference, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    TrackScratch *d = static_cast<TrackScratch *>(scratch(sizeof(TrackScratch), s));
+    if (!d) return;
+    TrackScratch h0;
+    h0.pose = load16(T16);
+    h0.tp.view = load16(view16);
+    h0.tp.have_reference = have_reference;
+    HIP_TRY(hipMemcpy(d, &h0, offsetof(TrackScratch, partials), hipMemcpyHostToDevice));
+    launch::track_reduce(out32 ? d->partials : nullptr, result_map, track_out, reinterpret_cast<const float4 *>(in_vertex4),
+                         reinterpret_cast<const float4 *>(in_normal4), in_w, in_h, reinterpret_cast<const float4 *>(ref_vertex4),
+                         reinterpret_cast<const float4 *>(ref_normal4), ref_w, ref_h, &d->pose, &d->tp, nullptr, dist_thr,
+                         normal_thr, s);
+    if (out32) launch::solve(nullptr, out32, d->partials, launch::track_blocks(in_w, in_h), 0, 0.f, 0, s);
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+void kfh_k_track(kfh_track_data *output, const float *in_vertex4, const float *in_normal4, uint32_t in_w, uint32_t in_h,
+                 const float *ref_vertex4, const float *ref_normal4, uint32_t ref_w, uint32_t ref_h, const float T16[16],
+                 const float view16[16], float dist_thr, float normal_thr, int32_t have_reference, void *stream) {
+    track_common(nullptr, nullptr, output, in_vertex4, in_normal4, in_w, in_h, ref_vertex4, ref_normal4, ref_w, ref_h, T16,
+                 view16, dist_thr, normal_thr, have_reference, (hipStream_t)stream);
+}
+
+void kfh_k_track_reduce(float *out32, int32_t *result_map, const float *in_vertex4, const float *in_normal4, uint32_t in_w,
+                        uint32_t in_h, const float *ref_vertex4, const float *ref_normal4, uint32_t ref_w, uint32_t ref_h,
+                        const float T16[16], const float view16[16], float dist_thr, float normal_thr, int32_t have_reference,
+                        void *stream) {
+    track_common(out32, result_map, nullptr, in_vertex4, in_normal4, in_w, in_h, ref_vertex4, ref_normal4, ref_w, ref_h, T16,
+                 view16, dist_thr, normal_thr, have_reference, (hipStream_t)stream);
+}
+
+void kfh_k_reduce(float *out8x32, const kfh_track_data *J, uint32_t j_w, uint32_t j_h, uint32_t w, uint32_t h, void *stream) {
+    (void)j_h;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    float *partials = static_cast<float *>(scratch(512 * 32 * sizeof(float), s));
+    if (!partials) return;
+    // rows 1..7 of the reference output hold per-block sums nobody reads (cpp:487-489); they are zero here
+    HIP_TRY(hipMemsetAsync(out8x32, 0, 8 * 32 * sizeof(float), s));
+    launch::reduce_trackdata(partials, J, j_w, w, h, s);
+    launch::solve(nullptr, out8x32, partials, launch::track_blocks(w, h), 0, 0.f, 0, s);
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+int kfh_k_update_pose(float *pose16, const float *reduction32, float icp_threshold, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    int *flag = static_cast<int *>(scratch(sizeof(int), s));
+    if (!flag) return KFH_ERR_HIP;
+    launch::update_pose(reinterpret_cast<M4 *>(pose16), reduction32, icp_threshold, flag, s);
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return h;
+}
+
+int kfh_k_check_pose(float *pose16, const float *old_pose16, const float *reduction32, uint32_t w, uint32_t h, float thr, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    int *flag = static_cast<int *>(scratch(sizeof(int), s));
+    if (!flag) return KFH_ERR_HIP;
+    launch::check_pose(reinterpret_cast<M4 *>(pose16), reinterpret_cast<const M4 *>(old_pose16), reduction32, w, h, thr, flag, s);
+    int hv = 0;
+    HIP_TRY(hipMemcpyAsync(&hv, flag, sizeof hv, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return hv;
+}
+
+void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], const float *depth, uint32_t w, uint32_t h,
+                     const float inv_track16[16], const float K16[16], float mu, float maxw, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    IntegrateParams *d = static_cast<IntegrateParams *>(scratch(sizeof(IntegrateParams), s));
+    if (!d) return;
+    IntegrateParams hp;
+    std::memset(&hp, 0, sizeof hp);
+    hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
+    HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
+    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, s);
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+static RayParams *upload_ray(const float view16[16], hipStream_t s) {
+    RayParams *d = static_cast<RayParams *>(scratch(sizeof(RayParams), s));
+    if (!d) return nullptr;
+    RayParams hp;
+    std::memset(&hp, 0, sizeof hp);
+    hp.view = load16(view16); hp.enabled = 1;
+    HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
+    return d;
+}
+
+void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const int16_t *vol, const uint32_t size[3],
+                   const float dim[3], const float view16[16], float near_plane, float far_plane, float step, float largestep,
+                   void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    RayParams *d = upload_ray(view16, s);
+    if (!d) return;
+    launch::raycast(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), w, h, vol, size[0], size[1], size[2],
+                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, s);
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+void kfh_k_render_depth(uint8_t *out, const float *depth, uint32_t w, uint32_t h, float near_plane, float far_plane, void *stream) {
+    launch::render_depth(reinterpret_cast<uchar4 *>(out), depth, w, h, near_plane, far_plane, (hipStream_t)stream);
+}
+
+void kfh_k_render_track(uint8_t *out, const int32_t *result_map, uint32_t w, uint32_t h, void *stream) {
+    launch::render_track(reinterpret_cast<uchar4 *>(out), result_map, w, h, (hipStream_t)stream);
+}
+
+void kfh_k_render_volume(uint8_t *out, uint32_t w, uint32_t h, const int16_t *vol, const uint32_t size[3], const float dim[3],
+                         const float view16[16], float near_plane, float far_plane, float step, float largestep,
+                         const float light[3], const float ambient[3], void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_scratch.mu);
+    RayParams *d = upload_ray(view16, s);
+    if (!d) return;
+    launch::render_volume(reinterpret_cast<uchar4 *>(out), w, h, vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), d,
+                          near_plane, far_plane, step, largestep, mk3(light[0], light[1], light[2]),
+                          mk3(ambient[0], ambient[1], ambient[2]), s);
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+}  // extern "C"

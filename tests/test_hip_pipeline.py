@@ -1,0 +1,153 @@
+"""Pipeline-level parity: class Kfusion on the GPU (through the C ABI) against the CPU twin, frame by frame.
+
+Reads like the reference driver (kfusion/src/benchmark.cpp:125-170): preprocessing -> tracking ->
+integration -> raycasting -> renders, same flags, same synthetic stream for both.
+"""
+import numpy as np
+import pytest
+
+from tests import util
+from tests.util import same_bits
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 10
+
+
+def _make(hip_mod, s, vol_res, pyramid=(10, 5, 4), ratio=1):
+    W, H = s.width // ratio, s.height // ratio
+    return hip_mod.Kfusion((W, H), vol_res, util.VOL_DIM, s.init_pos, pyramid)
+
+
+@pytest.fixture(scope="module")
+def kfmod(hip):
+    from slambench_amd import kfusion
+    return kfusion
+
+
+def _tsdf_diff_fraction(a, b):
+    """fraction of voxels whose TSDF differs by more than 1e-4 (in TSDF units of [-1, 1])."""
+    da = a[..., 0].astype(np.float64) / 32766.0
+    db = b[..., 0].astype(np.float64) / 32766.0
+    return float(np.mean(np.abs(da - db) > 1e-4))
+
+
+def test_lockstep_parity(hip, kfmod, orc):
+    """Both pipelines see the same pose at the start of every frame (the GPU pose is overwritten with the
+    oracle's), so every stage is compared on identical inputs: exact wherever the arithmetic allows."""
+    s = util.small_stream(N_FRAMES)
+    k = list(s.k)
+    res = (64, 64, 64)
+    g = _make(kfmod, s, res)
+    o = orc.OracleKfusion((s.width, s.height), res, util.VOL_DIM, s.init_pos)
+    for f in range(N_FRAMES):
+        g.set_pose(o.get_pose())
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        assert same_bits(g.buffer("floatDepth"), o.buffer("floatDepth"))
+        assert util.ulp_diff(g.buffer("scaledDepth0"), o.buffer("scaledDepth0")).max() <= 8
+        # feed the oracle's filtered depth to the GPU so that the rest of the frame is compared on equal inputs
+        g.write_buffer("scaledDepth0", o.buffer("scaledDepth0"))
+        tg = g.tracking(k, util.ICP_THRESHOLD, 1, f); to = o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        for l in range(3):
+            assert same_bits(g.buffer("scaledDepth%d" % l), o.buffer("scaledDepth%d" % l))
+            assert same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l))
+            assert same_bits(g.buffer("inputNormal%d" % l)[..., :3], o.buffer("inputNormal%d" % l))
+        assert tg == to, "tracked flag differs at frame %d" % f
+        pg, po = g.get_pose(), o.get_pose()
+        assert np.abs(pg - po).max() <= 2e-5, "pose after ICP differs at frame %d: %g" % (f, np.abs(pg - po).max())
+        assert np.array_equal(g.buffer("reduction")[28:32], o.buffer("reduction")[0, 28:32]) or f >= 4
+        g.set_pose(po)
+        ig = g.integration(k, 1, util.MU, f); io = o.integration(k, 1, util.MU, f)
+        assert ig == io
+        assert np.array_equal(g.buffer("volume"), o.buffer("volume")), "TSDF differs at frame %d" % f
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        assert same_bits(g.buffer("vertex")[..., :3], o.buffer("vertex"))
+        assert same_bits(g.buffer("normal")[..., :3], o.buffer("normal"))
+        assert np.array_equal(g.render_depth(), o.render_depth())
+        assert np.array_equal(g.render_volume(f, 2, k, 0.75 * util.MU), o.render_volume(f, 2, k, 0.75 * util.MU))
+    o.close(); g.close()
+
+
+@pytest.mark.parametrize("ratio,res,pyramid", [(1, (64, 64, 64), (10, 5, 4)), (2, (48, 48, 48), (4, 3)), (1, (32, 32, 32), (6,))])
+def test_free_running_parity(hip, kfmod, orc, ratio, res, pyramid):
+    """No synchronisation between the two runs: positions must stay within the north-star tolerance (1e-4 m),
+    flags must agree and the TSDF must differ in at most a depth-discontinuity handful of voxels."""
+    s = util.small_stream(N_FRAMES)
+    k = [v / ratio for v in s.k]
+    g = _make(kfmod, s, res, pyramid, ratio)
+    o = orc.OracleKfusion((s.width // ratio, s.height // ratio), res, util.VOL_DIM, s.init_pos, pyramid)
+    for f in range(N_FRAMES):
+        assert np.abs(g.get_position() - o.get_position()).max() <= 1e-4
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        o.get_tracked_flag = o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.get_tracked_flag
+        assert g.integration(k, 2, util.MU, f) == o.integration(k, 2, util.MU, f)
+        assert g.raycasting(k, util.MU, f) == o.raycasting(k, util.MU, f) == False  # noqa: E712 (cpp:975,984)
+        assert np.array_equal(g.render_track(), o.render_track()) or f >= 4
+    assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
+    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 2e-3
+    assert g.get_tracked() == o.get_tracked_flag and g.icp_iterations() > 0
+    o.close(); g.close()
+
+
+def test_compute_frame_equals_phases(hip, kfmod):
+    """Kfusion::computeFrame queued without host round trips gives the same bits as the four phase calls."""
+    s = util.small_stream(N_FRAMES)
+    k = list(s.k)
+    res = (64, 64, 64)
+    a, b = _make(kfmod, s, res), _make(kfmod, s, res)
+    for f in range(N_FRAMES):
+        a.preprocessing(s.depth_mm[f]); a.tracking(k, util.ICP_THRESHOLD, 1, f); a.integration(k, 2, util.MU, f); a.raycasting(k, util.MU, f)
+        b.compute_frame(s.depth_mm[f], (s.width, s.height), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+    b.synchronise()
+    assert same_bits(a.get_pose(), b.get_pose())
+    assert np.array_equal(a.buffer("volume"), b.buffer("volume"))
+    assert same_bits(a.buffer("vertex"), b.buffer("vertex"))
+    poses, tracked, integrated = b.frame_log(N_FRAMES)
+    assert same_bits(poses[-1], b.get_pose())
+    assert list(tracked[:4]) == [0, 0, 0, 0] and tracked[4:].all()
+    assert list(integrated[:4]) == [1, 1, 1, 1]                              # cpp:994: forced for frame <= 3
+    a.close(); b.close()
+
+
+def test_gating_rates(hip, kfmod, orc):
+    """tracking_rate / integration_rate gating (cpp:927, 994) including the stale-reduction re-check."""
+    s = util.small_stream(N_FRAMES)
+    k = list(s.k)
+    res = (32, 32, 32)
+    g = _make(kfmod, s, res)
+    o = orc.OracleKfusion((s.width, s.height), res, util.VOL_DIM, s.init_pos)
+    for f in range(N_FRAMES):
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        assert g.tracking(k, util.ICP_THRESHOLD, 2, f) == o.tracking(k, util.ICP_THRESHOLD, 2, f)
+        assert g.integration(k, 3, util.MU, f) == o.integration(k, 3, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+    assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
+    o.close(); g.close()
+
+
+def test_invalid_ratio_and_reset(hip, kfmod, orc):
+    s = util.small_stream(2)
+    g = kfmod.Kfusion((s.width, s.height), (16, 16, 16), util.VOL_DIM, s.init_pos)
+    with pytest.raises(ValueError):
+        g.preprocessing(np.zeros((100, 150), np.uint16))      # 150 < 160: cpp:566-569
+    k = list(s.k)
+    g.compute_frame(s.depth_mm[0], (s.width, s.height), k, 1, 1, util.ICP_THRESHOLD, util.MU, 0)
+    assert not np.array_equal(g.buffer("volume"), orc.init_volume((16, 16, 16)))
+    g.reset()
+    assert np.array_equal(g.buffer("volume"), orc.init_volume((16, 16, 16)))
+    g.close()
+
+
+def test_dump_volume(hip, kfmod, orc, tmp_path):
+    s = util.small_stream(5)
+    k = list(s.k)
+    res = (32, 32, 32)
+    g = _make(kfmod, s, res)
+    for f in range(5):
+        g.compute_frame(s.depth_mm[f], (s.width, s.height), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
+    path = str(tmp_path / "vol.bin")
+    assert g.dump_volume(path) == 0
+    dumped = np.fromfile(path, dtype=np.int16)
+    assert np.array_equal(dumped, g.buffer("volume")[..., 0].reshape(-1))    # cpp:1022-1026: tsdf shorts, x fastest
+    g.close()
