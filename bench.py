@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Throughput bench of the KinectFusion hot path on MI355X (contract: see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One *step* is one frame through preprocessing -> tracking (multi-level ICP) -> integration -> raycasting —
+the reference's `computation` column (kfusion/src/benchmark.cpp:164), the figure its README quotes — on the
+configuration BASELINE.json's metric is quoted on: 640x480 depth, `-c 1 -v 256 -y 10,5,4` and the reference
+Makefile's trajectory-2 flags `-s 4.8 -p 0.34,0.5,0.24 -k 481.2,480,320,240 -r 2`.  Depth frames are a seeded
+synthetic stream (no dataset offline) already resident in HBM when the timed region starts.  With N GPUs every
+rank runs its own independent stream (frames shard by stream; no data-path collective) and RCCL is used only
+for the barrier and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries `roofline` (dominant kernel,
+algorithmic bytes / HIP-event time measured in this run), `cpu_baseline` (the OpenMP oracle timed on the host
+cores on a bounded prefix of the same stream), `fps_total` (same loop plus the three renders and their
+read-back) and the ATE of the estimated trajectory against the generator's ground truth.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+CONFIGS = {
+    # name: (width, height, volume, pyramid, integration_rate, rendering_rate)
+    "cfg2": (640, 480, 256, (10, 5, 4), 2, 4),        # BASELINE.json configs[1]: default KFusion
+    "cfg3": (640, 480, 512, (10, 5, 4), 1, 1),        # configs[2]: HBM-bound integrate+raycast stress
+    "cfg4": (1280, 960, 512, (10, 5, 4, 4), 2, 4),    # configs[3]: 4-level ICP
+}
+MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, 1e-5, 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-total", action="store_true", help="skip the secondary loop with renders")
+    return ap.parse_args()
+
+
+def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_renders, dist):
+    """Warm up on frames [0, n_warm), time frames [n_warm, n_warm + n_steps).  Returns (seconds, kf)."""
+    W, H, vres, pyramid, irate, zrate = cfg
+    k = list(stream.k)
+    kf = kfusion.Kfusion((W, H), (vres,) * 3, (4.8,) * 3, stream.init_pos, pyramid, device=device)
+    frame_bytes = W * H * 2
+    base = d_depth.data_ptr()
+    renders = [np.zeros((H, W, 4), np.uint8) for _ in range(3)] if with_renders else None
+    import ctypes as C
+
+    def step(f):
+        kf.compute_frame(base + f * frame_bytes, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
+        if with_renders:   # benchmark.cpp:153-156
+            L, h = kf.L, kf.h
+            u8 = C.POINTER(C.c_uint8)
+            L.kfh_render_depth(h, renders[0].ctypes.data_as(u8), W, H)
+            L.kfh_render_track(h, renders[1].ctypes.data_as(u8), W, H)
+            L.kfh_render_volume(h, renders[2].ctypes.data_as(u8), W, H, f, zrate, (C.c_float * 4)(*k), 0.75 * MU)
+
+    for f in range(n_warm):
+        step(f)
+    kf.synchronise()
+    if not with_renders:
+        kf.set_profiling(["integrate", "raycast"])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for f in range(n_warm, n_warm + n_steps):
+        step(f)
+    kf.synchronise()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    return elapsed, kf
+
+
+def cpu_baseline(stream, cfg, budget_s, max_frames):
+    """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only)."""
+    from oracle import orc
+    orc.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # cgroup CPU quota of the box (a one-GPU share is 16 CPUs)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per))))
+    except Exception:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    W, H, vres, pyramid, irate, _ = cfg
+    k = list(stream.k)
+    o = orc.OracleKfusion((W, H), (vres,) * 3, (4.8,) * 3, stream.init_pos, pyramid, omp=True)
+    n, spent = 0, 0.0
+    while n < max_frames and (spent < budget_s or n < 8):
+        t = time.perf_counter()
+        o.preprocessing(stream.depth_mm[n]); o.tracking(k, ICP_THRESHOLD, TRACKING_RATE, n)
+        o.integration(k, irate, MU, n); o.raycasting(k, MU, n)
+        spent += time.perf_counter() - t
+        n += 1
+    # V of SURVEY §8(d) (distinct voxels a raycast samples) — counted on two more frames, outside the timing
+    o.set_counting(True)
+    vs = []
+    for f in range(n, min(n + 2, max_frames)):
+        o.preprocessing(stream.depth_mm[f]); o.tracking(k, ICP_THRESHOLD, TRACKING_RATE, f)
+        o.integration(k, irate, MU, f); o.raycasting(k, MU, f)
+        vs.append(o.counters()["raycast_distinct_voxels"])
+    o.close()
+    return {"value": n / spent, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "first %d frames of the same stream, OpenMP oracle (liborc_omp.so), %d threads, %.1f s" % (n, cores, spent)}, \
+        (float(np.mean(vs)) if vs else None)
+
+
+def main():
+    args = parse()
+    import torch
+    from slambench_amd import checkpos, kfusion, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    cfg = CONFIGS[args.config]
+    W, H, vres, pyramid, irate, zrate = cfg
+    n_frames = args.warmup + args.steps
+    # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
+    stream = synth.cached_stream(n_frames, W, H, seed=1234, variant=rank % 4)
+    d_depth = torch.from_numpy(stream.depth_mm.view(np.int16)).cuda()
+
+    elapsed, kf = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, False, dist)
+    prof = kf.read_profile()
+    updated = kf.integrate_updated()
+    icp_iters = kf.icp_iterations()
+    fallbacks = kf.solve_fallbacks()
+    poses, tracked, integrated = kf.frame_log(n_frames)
+    kf.close()
+
+    # aggregate: max time over ranks, frames summed
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_max = float(t.item())
+    total_frames = args.steps * world
+
+    fps_total = None
+    if not args.no_total:
+        e2, kf2 = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, True, dist)
+        kf2.close()
+        t2 = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        fps_total = total_frames / float(t2.item())
+
+    # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
+    pos_after = poses[:, :3, 3] - stream.init_pos.astype(np.float32)
+    rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
+    errs = checkpos.ate([tuple(r) for r in rows], [tuple(g) for g in synth.ground_truth_rows(stream)])
+    ate = {"mean": float(np.mean(errs)), "max": float(np.max(errs)), "frames": len(errs),
+           "untracked": int((tracked == 0).sum())}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    cpu, v_distinct = (None, None)
+    if not args.no_cpu_baseline and world == 1:
+        cpu, v_distinct = cpu_baseline(stream, cfg, args.cpu_seconds, n_frames)
+
+    P = W * H
+    roof = {}
+    for name in ("integrate", "raycast"):
+        ms, n = prof[name]
+        if not n:
+            continue
+        avg_s = ms / n * 1e-3
+        if name == "integrate":
+            alg = 8.0 * (updated / max(1, int(integrated.sum()))) + 4.0 * P      # 8*U + 4*P  
+        else:
+            alg = 24.0 * P + 4.0 * (v_distinct if v_distinct else 0.0)            # 24*P + 4*V
+        gbs = alg / avg_s / 1e9
+        roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                      "algorithmic_bytes_per_launch": round(alg)}
+    dominant = max(roof, key=lambda k: prof[k][0]) if roof else None
+    out = {
+        "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), living-room-like stream 640x480 -c 1 @256^3",
+        "value": round(total_frames / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d depth, -c 1 -v %d -y %s -r %d -z %d -s 4.8 -p 0.34,0.5,0.24 -k 481.2,480,320,240 -m 0.1, one stream per GPU"
+                               % (args.config, W, H, vres, ",".join(map(str, pyramid)), irate, zrate),
+                   "frames_per_gpu": args.steps, "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks},
+        "fps_total": None if fps_total is None else round(fps_total, 2),
+        "ate_m": ate,
+        "roofline": roof.get(dominant),
+        "roofline_other": {k: v for k, v in roof.items() if k != dominant},
+        "cpu_baseline": cpu,
+    }
+    if args.config != "cfg2":
+        out["metric"] = out["metric"].replace("640x480 -c 1 @256^3", "%dx%d -c 1 @%d^3" % (W, H, vres))
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

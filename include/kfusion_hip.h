@@ -118,6 +118,8 @@ int kfh_read_frame_log(kfh_context *ctx, uint32_t n, float *poses16_out, int32_t
 uint64_t kfh_icp_iterations(kfh_context *ctx);
 /* Voxels updated by all integrate launches so far (U of SURVEY.md §8d; device counter). */
 uint64_t kfh_integrate_updated(kfh_context *ctx);
+/* ICP solves whose normal equations were too ill-conditioned for the LDL^T fast path (device counter). */
+uint64_t kfh_solve_fallbacks(kfh_context *ctx);
 
 /* Per-phase device time from HIP events recorded on the context's stream around each launch group
  * (the role of the reference's KERNEL_TIMINGS TICK/TOCK, cpp/kernels.cpp:31-35).  phase_mask has bit

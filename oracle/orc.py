@@ -80,6 +80,7 @@ def lib(omp: bool = False):
         "orc_kfusion_get_position": (None, [vp, fp]),
         "orc_kfusion_dump_volume": (i, [vp, C.c_char_p]),
         "orc_kfusion_counters": (cp, [vp]),
+        "orc_kfusion_set_counting": (None, [vp, i]),
         "orc_kfusion_buffer": (vp, [vp, C.c_char_p, C.POINTER(C.c_ulonglong)]),
     }
     for name_, (res, args) in sig.items():
@@ -362,6 +363,9 @@ class OracleKfusion:
 
     def dump_volume(self, path):
         return self.L.orc_kfusion_dump_volume(self.h, path.encode())
+
+    def set_counting(self, raycast_distinct=True):
+        self.L.orc_kfusion_set_counting(self.h, 1 if raycast_distinct else 0)
 
     def counters(self):
         c = self.L.orc_kfusion_counters(self.h).contents

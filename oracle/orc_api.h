@@ -62,6 +62,7 @@ void orc_kfusion_set_pose(orc_kfusion *, const float in16[16]);
 void orc_kfusion_get_position(orc_kfusion *, float out3[3]);
 int orc_kfusion_dump_volume(orc_kfusion *, const char *filename);
 orc_counters *orc_kfusion_counters(orc_kfusion *);
+void orc_kfusion_set_counting(orc_kfusion *, int raycast_distinct);
 // Internal buffers for parity checks.  name: "floatDepth", "scaledDepth<l>", "inputVertex<l>",
 // "inputNormal<l>", "vertex", "normal", "trackingResult", "reduction", "volume", "raycastPose", "oldPose".
 // Returns a borrowed pointer and writes the byte size (0 if unknown).

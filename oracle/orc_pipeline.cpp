@@ -43,6 +43,7 @@ struct orc_kfusion {
     std::vector<TrackRec> trackingResult;
     std::vector<short> volume;
     orc_counters counters;
+    bool count_raycast;   // V instrumentation costs a pass over the volume: off unless asked for
 };
 
 static inline unsigned level_div(unsigned v, int l) { return v / (unsigned)(int)pow(2, l); }
@@ -85,6 +86,7 @@ orc_kfusion *orc_kfusion_create(unsigned W, unsigned H, const unsigned volRes[3]
     orc_gaussian(k->gaussian.data(), radius, delta);
     k->volume.assign((size_t)2 * volRes[0] * volRes[1] * volRes[2], 0);
     std::memset(&k->counters, 0, sizeof k->counters);
+    k->count_raycast = false;
     orc_kfusion_reset(k);
     return k;
 }
@@ -162,7 +164,7 @@ int orc_kfusion_raycasting(orc_kfusion *k, const float k4[4], float mu, unsigned
         const f4 kk = {k4[0], k4[1], k4[2], k4[3]};
         const M4 view = matmul(k->raycastPose, inverse_camera_matrix(kk));
         orc_raycast(k->vertex.data(), k->normal.data(), k->W, k->H, k->volume.data(), k->volRes, k->volDim,
-                    &view.m[0][0], nearPlane, farPlane, k->step, 0.75f * mu, &k->counters);
+                    &view.m[0][0], nearPlane, farPlane, k->step, 0.75f * mu, k->count_raycast ? &k->counters : nullptr);
     }
     return 0;
 }
@@ -206,6 +208,7 @@ int orc_kfusion_dump_volume(orc_kfusion *k, const char *filename) {
 }
 
 orc_counters *orc_kfusion_counters(orc_kfusion *k) { return &k->counters; }
+void orc_kfusion_set_counting(orc_kfusion *k, int raycast_distinct) { k->count_raycast = raycast_distinct != 0; }
 
 void *orc_kfusion_buffer(orc_kfusion *k, const char *name, unsigned long long *nbytes) {
     const std::string n(name);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kfh_read_frame_log": (i32, [vp, u, fp, i32p, i32p]),
     "kfh_icp_iterations": (u64, [vp]),
     "kfh_integrate_updated": (u64, [vp]),
+    "kfh_solve_fallbacks": (u64, [vp]),
     "kfh_set_profiling": (None, [vp, u]),
     "kfh_read_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "kfh_read_buffer": (i64, [vp, cstr, vp, u64]),

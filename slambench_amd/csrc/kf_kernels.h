@@ -28,6 +28,7 @@ struct DevState {
     int level_done[KFH_MAX_LEVELS];
     unsigned long long icp_iterations;
     unsigned long long integrate_updated;   // U of SURVEY §8(d), summed over all integrate launches
+    unsigned long long solve_fallbacks;     // ICP solves that needed the Jacobi path (ill-conditioned J^T J)
 };
 
 struct FrameLogEntry { M4 pose; int tracked; int integrated; int frame; int pad; };
@@ -54,6 +55,7 @@ struct ControlArgs {
 
 namespace launch {
 unsigned track_blocks(unsigned w, unsigned h);
+unsigned track_blocks_max();
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
                 const Gauss5 &g, float e_d, hipStream_t s);

@@ -11,6 +11,8 @@
 // keeping the pose on the device so the 19-iteration ICP loop never round-trips to the host.
 #include "kf_kernels.h"
 
+#include <cstdlib>
+
 namespace kf {
 
 // =====================================================================================
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(PBX *PBY) void k_vertex_normal(float4 *__restrict__
 // respect to the serial CPU order, which is the one float difference this path has by design.
 // =====================================================================================
 constexpr int TR_THREADS = 256;
-constexpr unsigned TR_MAX_BLOCKS = 512;
+constexpr unsigned TR_MAX_BLOCKS = 2048;
 
 struct PixelTrack { int result; float error; float J[6]; };
 
@@ -234,23 +236,39 @@ __device__ __forceinline__ void accumulate(float (&acc)[32], int result, float e
     acc[28] += 1.f;
 }
 
-// 256 threads -> one 32-float partial.  Fixed tree: wave64 shuffle, then waves 0..3 in order.
+// 256 threads -> one 32-float partial.  Fixed tree, so the result is bitwise reproducible.
+// Wave step: a halving butterfly.  At each of five steps a lane keeps one half of its remaining values
+// and hands the other half to its partner (lane ^ 32, 16, 8, 4, 2), so 32 values x 64 lanes collapse to
+// one value per lane with 16+8+4+2+1 shuffles instead of 32x6; a last exchange with lane ^ 1 completes
+// the sum.  Lane l ends up owning sum index ((l>>5)&1)*16 + ((l>>4)&1)*8 + ((l>>3)&1)*4 + ((l>>2)&1)*2 + ((l>>1)&1).
+template <int N>
+__device__ __forceinline__ void halve(const float (&in)[2 * N], float (&out)[N], bool hi, int partner) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float keep = hi ? in[i + N] : in[i];
+        const float give = hi ? in[i] : in[i + N];
+        out[i] = keep + __shfl_xor(give, partner, 64);
+    }
+}
+
 __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__restrict__ partial) {
     __shared__ float sm[TR_THREADS / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        float v = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) sm[wave][i] = v;
-    }
+    float a16[16], a8[8], a4[4], a2[2], a1[1];
+    halve<16>(acc, a16, lane & 32, 32);
+    halve<8>(a16, a8, lane & 16, 16);
+    halve<4>(a8, a4, lane & 8, 8);
+    halve<2>(a4, a2, lane & 4, 4);
+    halve<1>(a2, a1, lane & 2, 2);
+    const float v = a1[0] + __shfl_xor(a1[0], 1, 64);
+    const int index = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) sm[wave][index] = v;
     __syncthreads();
     if (threadIdx.x < 32) {
-        float v = sm[0][threadIdx.x];
+        float t = sm[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < TR_THREADS / 64; ++w) v += sm[w][threadIdx.x];
-        partial[threadIdx.x] = v;
+        for (int w = 1; w < TR_THREADS / 64; ++w) t += sm[w][threadIdx.x];
+        partial[threadIdx.x] = t;
     }
 }
 
@@ -309,9 +327,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_reduce_trackdata(float *__restri
 //   x = pinv(J^T J) J^T e (double), pose <- exp(x) * pose (float), level done when |x| < icp_threshold.
 // One block; the pose never leaves HBM between ICP iterations.
 // =====================================================================================
-__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold) {
+__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold, bool &fast) {
     double x[6];
-    solve6(red + 1, x);
+    fast = solve6_ldlt(red + 1, x);
+    if (!fast) solve6(red + 1, x);
     const M4 delta = se3_exp_to_m4(x);
     pose = matmul(delta, pose);
     double n2 = 0.0;
@@ -319,21 +338,21 @@ __device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float i
     return sqrt(n2) < icp_threshold;
 }
 
-__global__ __launch_bounds__(256) void k_solve(DevState *__restrict__ st, float *__restrict__ out32,
-                                               const float *__restrict__ partials, unsigned nblocks, int level,
-                                               float icp_threshold, int do_solve) {
+__global__ __launch_bounds__(1024) void k_solve(DevState *__restrict__ st, float *__restrict__ out32,
+                                                const float *__restrict__ partials, unsigned nblocks, int level,
+                                                float icp_threshold, int do_solve) {
     if (st && do_solve && st->level_done[level]) return;
-    __shared__ float sm[8][32];
+    __shared__ float sm[32][33];
     __shared__ float red[32];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     float acc = 0.f;
-    for (unsigned b = g; b < nblocks; b += 8) acc += partials[(size_t)b * 32 + c];
+    for (unsigned b = g; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + c];
     sm[g][c] = acc;
     __syncthreads();
     if (threadIdx.x < 32) {
         float v = sm[0][threadIdx.x];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v += sm[k][threadIdx.x];
+        for (int k = 1; k < 32; ++k) v += sm[k][threadIdx.x];
         red[threadIdx.x] = v;
         if (out32) out32[threadIdx.x] = v;
         if (st) st->reduction[threadIdx.x] = v;
@@ -341,9 +360,11 @@ __global__ __launch_bounds__(256) void k_solve(DevState *__restrict__ st, float 
     __syncthreads();
     if (threadIdx.x == 0 && st && do_solve) {
         M4 pose = st->pose;
-        const bool converged = apply_update(pose, red, icp_threshold);
+        bool fast = true;
+        const bool converged = apply_update(pose, red, icp_threshold, fast);
         st->pose = pose;
         st->icp_iterations += 1;
+        if (!fast) st->solve_fallbacks += 1;
         if (converged) st->level_done[level] = 1;
     }
 }
@@ -353,7 +374,8 @@ __global__ void k_update_pose(M4 *pose, const float *reduction32, float icp_thre
     M4 p = *pose;
     float red[32];
     for (int i = 0; i < 32; ++i) red[i] = reduction32[i];
-    const bool c = apply_update(p, red, icp_threshold);
+    bool fast;
+    const bool c = apply_update(p, red, icp_threshold, fast);
     *pose = p;
     *converged = c ? 1 : 0;
 }
@@ -445,8 +467,15 @@ __global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__
 // a full 256-byte line of the x-fastest short2 grid.  The camera-space position is carried along z by
 // repeated addition exactly like the CPU loop (cpp:645-646); a thread that starts at z0 > 0 first replays
 // the z0 additions in registers so that its float state carries the bits of the serial march.
-// Voxels are read only when all four tests pass: algorithmic traffic is 8*U + 4*P bytes.
+//
+// The z march is processed in batches of IB voxels: first the geometry of the whole batch (the four
+// reject tests need no memory), then all depth gathers and voxel reads of the batch are issued together,
+// then the updates.  A column therefore has up to 2*IB loads in flight instead of two dependent round
+// trips per voxel, which is what bounded the first version (64 us at 256^3 = 64 z-steps x ~1 us).
+// The voxel read is issued for every voxel that projects into the image (it is needed unless the depth is
+// 0 or the voxel lies more than mu behind the surface); traffic stays within a few MB of 8*U + 4*P.
 // =====================================================================================
+template <int IB>
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
@@ -455,35 +484,58 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     unsigned updated = 0;
     if (x < sx && y < sy) {
-    const M4 invTrack = ip->invTrack, K = ip->K;
-    const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
-    const f3 cameraDelta = rotate(K, delta);
-    f3 pos = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
-    f3 cam = xform(K, pos);
-    const unsigned z0 = blockIdx.z * zchunk;
-    const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
-    for (unsigned z = 0; z < z0; ++z) { pos = add3(pos, delta); cam = add3(cam, cameraDelta); }
-    const size_t plane = (size_t)sx * sy;
-    short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    for (unsigned z = z0; z < z1; ++z, pos = add3(pos, delta), cam = add3(cam, cameraDelta), cell += plane) {
-        if (pos.z < 0.0001f) continue;
-        const float px = cam.x / cam.z + 0.5f, py = cam.y / cam.z + 0.5f;
-        if (px < 0 || px > wm1 || py < 0 || py > hm1) continue;
-        const unsigned ux = (unsigned)px, uy = (unsigned)py;
-        const float d = depth[ux + uy * W];
-        if (d == 0) continue;
-        const float diff = (d - cam.z) * sqrtf(1 + sq(pos.x / pos.z) + sq(pos.y / pos.z));
-        if (diff > -mu) {
-            const float sdf = fmin_h(1.f, diff / mu);
-            const short2 c = *cell;
-            float tsdf = c.x * kShort2Float, w = c.y;
-            tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
-            w = fmin_h(w + 1, maxweight);
-            *cell = make_short2((short)(tsdf * 32766.0f), (short)w);
-            ++updated;
+        const M4 invTrack = ip->invTrack, K = ip->K;
+        const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
+        const f3 cameraDelta = rotate(K, delta);
+        f3 pos = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
+        f3 cam = xform(K, pos);
+        const unsigned z0 = blockIdx.z * zchunk;
+        const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
+        for (unsigned z = 0; z < z0; ++z) { pos = add3(pos, delta); cam = add3(cam, cameraDelta); }
+        const size_t plane = (size_t)sx * sy;
+        short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
+        const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+        for (unsigned zb = z0; zb < z1; zb += IB, cell += (size_t)IB * plane) {
+            unsigned live = 0;            // bit i: voxel zb+i projects into the image
+            unsigned pix[IB];
+            float camz[IB], fac[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                if (zb + i < z1) {
+                    if (!(pos.z < 0.0001f)) {                                   // cpp:647
+                        const float px = cam.x / cam.z + 0.5f, py = cam.y / cam.z + 0.5f;
+                        if (!(px < 0 || px > wm1 || py < 0 || py > hm1)) {      // cpp:651-653
+                            live |= 1u << i;
+                            pix[i] = (unsigned)px + (unsigned)py * W;
+                            camz[i] = cam.z;
+                            fac[i] = sqrtf(1 + sq(pos.x / pos.z) + sq(pos.y / pos.z));
+                        }
+                    }
+                    pos = add3(pos, delta);
+                    cam = add3(cam, cameraDelta);
+                }
+            }
+            if (!live) continue;
+            float d[IB];
+            short2 c[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                if (live & (1u << i)) { d[i] = depth[pix[i]]; c[i] = cell[(size_t)i * plane]; }
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                if (!(live & (1u << i))) continue;
+                if (d[i] == 0) continue;                                        // cpp:655
+                const float diff = (d[i] - camz[i]) * fac[i];
+                if (diff > -mu) {
+                    const float sdf = fmin_h(1.f, diff / mu);
+                    float tsdf = c[i].x * kShort2Float, w = c[i].y;
+                    tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
+                    w = fmin_h(w + 1, maxweight);
+                    cell[(size_t)i * plane] = make_short2((short)(tsdf * 32766.0f), (short)w);
+                    ++updated;
+                }
+            }
         }
-    }
     }
     // instrumentation (U = voxels that passed all four tests): one atomic per wave
     if (updated_total) {
@@ -527,13 +579,32 @@ __device__ __forceinline__ Taps locate(const VolView &v, f3 pos) {
     return t;
 }
 
+// Two x-adjacent voxels in one 8-byte load.  The trilinear taps come in x-pairs (lo.x, up.x) with
+// up.x in {lo.x, lo.x + 1}; p = min(lo.x, sx - 2) makes [p, p + 1] cover both without leaving the row, so the
+// eight 2-byte gathers of an interpolation become four 8-byte ones (the ray march is bound by the texture
+// address path, not by bytes).  The values are the same shorts, so the result is bit-identical.
+struct __attribute__((packed, aligned(4))) VoxelPair { int a, b; };
+
+__device__ __forceinline__ void tap_pair(const VolView &v, int p, int y, int z, bool lo_first, bool up_first, float &vlo,
+                                         float &vup) {
+    const VoxelPair q = *reinterpret_cast<const VoxelPair *>(v.data + (size_t)p + (size_t)y * v.sx + (size_t)z * v.plane);
+    const float first = (float)(short)q.a, second = (float)(short)q.b;   // .x is the low half of each short2
+    vlo = lo_first ? first : second;
+    vup = up_first ? first : second;
+}
+
 __device__ __forceinline__ float interp(const VolView &v, f3 pos) {
     const Taps t = locate(v, pos);
     const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
-    return (((tap(v, t.lo[0], t.lo[1], t.lo[2]) * (1 - fx) + tap(v, t.up[0], t.lo[1], t.lo[2]) * fx) * (1 - fy)
-             + (tap(v, t.lo[0], t.up[1], t.lo[2]) * (1 - fx) + tap(v, t.up[0], t.up[1], t.lo[2]) * fx) * fy) * (1 - fz)
-            + ((tap(v, t.lo[0], t.lo[1], t.up[2]) * (1 - fx) + tap(v, t.up[0], t.lo[1], t.up[2]) * fx) * (1 - fy)
-               + (tap(v, t.lo[0], t.up[1], t.up[2]) * (1 - fx) + tap(v, t.up[0], t.up[1], t.up[2]) * fx) * fy) * fz)
+    const int p = imax(imin(t.lo[0], v.sx - 2), 0);
+    const bool lf = t.lo[0] == p, uf = t.up[0] == p;
+    float a0, a1, b0, b1, c0, c1, d0, d1;
+    tap_pair(v, p, t.lo[1], t.lo[2], lf, uf, a0, a1);
+    tap_pair(v, p, t.up[1], t.lo[2], lf, uf, b0, b1);
+    tap_pair(v, p, t.lo[1], t.up[2], lf, uf, c0, c1);
+    tap_pair(v, p, t.up[1], t.up[2], lf, uf, d0, d1);
+    return (((a0 * (1 - fx) + a1 * fx) * (1 - fy) + (b0 * (1 - fx) + b1 * fx) * fy) * (1 - fz)
+            + ((c0 * (1 - fx) + c1 * fx) * (1 - fy) + (d0 * (1 - fx) + d1 * fx) * fy) * fz)
            * kShort2Float;
 }
 
@@ -739,10 +810,25 @@ namespace launch {
 static inline dim3 grid_rows(unsigned W, unsigned H) { return dim3((W + 63) / 64, (H + 3) / 4); }
 static inline dim3 block_rows() { return dim3(64, 4); }
 
+static unsigned track_block_cap() {
+    static unsigned cap = 0;
+    if (!cap) {
+        // tuning knob.  Measured at 640x480 (profiles/r01_sweeps.md): 512 blocks (2.3 pixels per thread, 64 KB of
+        // partials for k_solve to add up) beats one pixel per thread (1200 blocks) by 4-5 % of the frame time.
+        const char *e = getenv("KFH_TRACK_BLOCKS");
+        const long v = e ? atol(e) : 0;
+        cap = (v >= 1 && v <= (long)TR_MAX_BLOCKS) ? (unsigned)v : 512;
+    }
+    return cap;
+}
+
 unsigned track_blocks(unsigned w, unsigned h) {
     const unsigned n = (w * h + TR_THREADS - 1) / TR_THREADS;
-    return n < 1 ? 1 : (n > TR_MAX_BLOCKS ? TR_MAX_BLOCKS : n);
+    const unsigned cap = track_block_cap();
+    return n < 1 ? 1 : (n > cap ? cap : n);
 }
+
+unsigned track_blocks_max() { return TR_MAX_BLOCKS; }
 
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
     const size_t n = (size_t)sx * sy * sz;
@@ -797,7 +883,7 @@ void reduce_trackdata(float *partials, const kfh_track_data *J, unsigned JW, uns
 
 void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, int level, float icp_threshold,
            int do_solve, hipStream_t s) {
-    k_solve<<<1, 256, 0, s>>>(st, out32, partials, nblocks, level, icp_threshold, do_solve);
+    k_solve<<<1, 1024, 0, s>>>(st, out32, partials, nblocks, level, icp_threshold, do_solve);
 }
 
 void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s) {
@@ -812,18 +898,29 @@ void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned 
     k_check_pose<<<1, 64, 0, s>>>(pose, oldPose, reduction32, W, H, thr, ok);
 }
 
+static long env_long(const char *name, long lo, long hi, long dflt) {
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const long v = atol(e);
+    return (v >= lo && v <= hi) ? v : dflt;
+}
+
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, hipStream_t s) {
-    // enough z-chunks to put >= ~4096 waves in flight on 256 CUs; each chunk replays z0 additions
+    // enough z-chunks to put >= ~8192 waves in flight on 256 CUs; each chunk replays its z0 additions
+    static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
+    static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 8, 8);
     const unsigned waves_xy = ((sx + 63) / 64) * sy;
-    unsigned nchunks = (4096 + waves_xy - 1) / waves_xy;
+    unsigned nchunks = chunks_env ? (unsigned)chunks_env : (8192 + waves_xy - 1) / waves_xy;
     if (nchunks < 1) nchunks = 1;
-    if (nchunks > 8) nchunks = 8;
+    if (!chunks_env && nchunks > 16) nchunks = 16;
     if (nchunks > sz) nchunks = sz;
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
     const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
-    k_integrate<<<grid, block_rows(), 0, s>>>(reinterpret_cast<short2 *>(vol), sx, sy, sz, dim, depth, W, H, p, mu,
-                                               maxweight, zchunk, updated_total);
+    short2 *v = reinterpret_cast<short2 *>(vol);
+    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
+    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
+    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
 }
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,

@@ -227,4 +227,79 @@ __host__ __device__ inline void solve6(const float *vals, double x[6]) {
     }
 }
 
+// Fast path of the same solve.  When C is comfortably positive definite the pseudo-inverse of
+// commons.h:403 keeps every singular value, so x = C^-1 b, and an LDL^T factorisation (6 divisions, no
+// square roots, no iteration) gives it to the same ~1e-12.  The factorisation certifies its own use:
+// cond_2(C) <= |C|_F * |C^-1|_F, so when that product is below 5e5 no singular value can fall under the
+// reference's max/1e6 cut-off and the two solves agree.  Otherwise (the all-zero system of frames 0-3,
+// degenerate geometry) the caller falls back to solve6.  The Frobenius bound over-estimates the
+// condition number by at most 6x, so every system with cond < 8e4 takes the fast path.
+__host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
+    double L[6][6], d[6], b[6];
+    double c_f2 = 0.0, tr = 0.0;
+    {
+        int p = 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                const double v = vals[p]; ++p;
+                L[c][r] = v;   // lower triangle holds C
+                c_f2 += (c == r) ? v * v : 2.0 * v * v;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { b[i] = vals[i]; tr += L[i][i]; }
+    if (!(tr > 0.0)) return false;
+    const double tiny = tr * 1e-9;
+    // in-place LDL^T: L[i][j] (i > j) becomes the unit-lower factor, d the diagonal
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double dj = L[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * d[k];
+        if (!(dj > tiny)) return false;
+        d[j] = dj;
+        const double inv = 1.0 / dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = L[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v * inv;
+        }
+    }
+    // M = L^-1 (unit lower triangular), column by column
+    double M[6][6], invd[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        invd[c] = 1.0 / d[c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r < c) { M[r][c] = 0.0; continue; }
+            if (r == c) { M[r][c] = 1.0; continue; }
+            double v = 0.0;
+#pragma unroll
+            for (int k = c; k < r; ++k) v -= L[r][k] * M[k][c];
+            M[r][c] = v;
+        }
+    }
+    // C^-1 = M^T D^-1 M (symmetric): entries, Frobenius norm and x = C^-1 b in one sweep
+    double inv_f2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = j; k < 6; ++k) v += M[k][i] * M[k][j] * invd[k];
+            inv_f2 += (i == j) ? v * v : 2.0 * v * v;
+            x[i] += v * b[j];
+            if (i != j) x[j] += v * b[i];
+        }
+    return c_f2 * inv_f2 < 5e5 * 5e5;
+}
+
 }  // namespace kf

@@ -269,7 +269,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_vertex, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_normal, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_result, P * sizeof(int)));
-    ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)launch::track_blocks(width, height) * 32 * sizeof(float)));
+    ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)launch::track_blocks_max() * 32 * sizeof(float)));
     ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
     ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
     ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
@@ -413,8 +413,10 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
     ControlArgs a;
     fill_control(c, a, k, frame, tracking_rate, integration_rate);
     launch::control(c->d_state, c->d_log, OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
-    enqueue_integrate(c, mu);
-    enqueue_raycast(c, mu);
+    // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the
+    // integrate gate (tracking verdict) is the device flag the kernel reads
+    if ((frame % integration_rate) == 0 || frame <= 3) enqueue_integrate(c, mu);
+    if (frame > 2) enqueue_raycast(c, mu);
     c->mirror_stale = true;
     return KFH_OK;
 }
@@ -507,6 +509,7 @@ int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracke
     return KFH_OK;
 }
 
+uint64_t kfh_solve_fallbacks(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->solve_fallbacks; }
 uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
 
 void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
@@ -649,7 +652,7 @@ void kfh_k_vertex_normal(float *vertex4, float *normal4, const float *depth, uin
     launch::vertex_normal(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), depth, w, h, load16(invK16), (hipStream_t)stream);
 }
 
-struct TrackScratch { M4 pose; TrackParams tp; float partials[512 * 32]; };
+struct TrackScratch { M4 pose; TrackParams tp; float partials[2048 * 32]; };
 
 static void track_common(float *out32, int32_t *result_map, kfh_track_data *track_out, const float *in_vertex4,
                          const float *in_normal4, uint32_t in_w, uint32_t in_h, const float *ref_vertex4,
@@ -690,7 +693,7 @@ void kfh_k_reduce(float *out8x32, const kfh_track_data *J, uint32_t j_w, uint32_
     (void)j_h;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
-    float *partials = static_cast<float *>(scratch(512 * 32 * sizeof(float), s));
+    float *partials = static_cast<float *>(scratch(2048 * 32 * sizeof(float), s));
     if (!partials) return;
     // rows 1..7 of the reference output hold per-block sums nobody reads (cpp:487-489); they are zero here
     HIP_TRY(hipMemsetAsync(out8x32, 0, 8 * 32 * sizeof(float), s));

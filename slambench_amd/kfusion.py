@@ -153,6 +153,9 @@ class Kfusion:
     def icp_iterations(self):
         return int(self.L.kfh_icp_iterations(self.h))
 
+    def solve_fallbacks(self):
+        return int(self.L.kfh_solve_fallbacks(self.h))
+
     def integrate_updated(self):
         return int(self.L.kfh_integrate_updated(self.h))
 
