@@ -129,11 +129,9 @@ def cpu_baseline(stream, cfg, budget_s, max_frames):
 def main():
     args = parse()
     import torch
-    from slambench_amd import checkpos, kfusion, synth
+    from slambench_amd import checkpos, kfusion, multi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = multi.env_rank()
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -150,7 +148,7 @@ def main():
     W, H, vres, pyramid, irate, zrate = cfg
     n_frames = args.warmup + args.steps
     # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
-    stream = synth.cached_stream(n_frames, W, H, seed=1234, variant=rank % 4)
+    stream = synth.cached_stream(n_frames, W, H, seed=1234, variant=multi.stream_variant(rank))
     d_depth = torch.from_numpy(stream.depth_mm.view(np.int16)).cuda()
 
     elapsed, kf = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, False, dist)
@@ -161,28 +159,22 @@ def main():
     poses, tracked, integrated = kf.frame_log(n_frames)
     kf.close()
 
-    # aggregate: max time over ranks, frames summed
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_max = float(t.item())
-    total_frames = args.steps * world
+    # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
+    pos_after = poses[:, :3, 3] - stream.init_pos.astype(np.float32)
+    rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
+    errs = checkpos.ate([tuple(r) for r in rows], [tuple(g) for g in synth.ground_truth_rows(stream)])
+
+    # whole-job aggregate: frames summed over ranks / max time over ranks (one small all-reduce on RCCL)
+    job = multi.aggregate(multi.RankStats(args.steps, elapsed, float(np.sum(errs)), float(np.max(errs)), int((tracked == 0).sum())),
+                          dist, device="cuda")
+    t_max, total_frames = job.seconds, job.frames
+    ate = {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs), "untracked_all_ranks": job.untracked}
 
     fps_total = None
     if not args.no_total:
         e2, kf2 = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, True, dist)
         kf2.close()
-        t2 = torch.tensor([e2], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        fps_total = total_frames / float(t2.item())
-
-    # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
-    pos_after = poses[:, :3, 3] - stream.init_pos.astype(np.float32)
-    rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
-    errs = checkpos.ate([tuple(r) for r in rows], [tuple(g) for g in synth.ground_truth_rows(stream)])
-    ate = {"mean": float(np.mean(errs)), "max": float(np.max(errs)), "frames": len(errs),
-           "untracked": int((tracked == 0).sum())}
+        fps_total = multi.aggregate(multi.RankStats(args.steps, e2), dist, device="cuda").fps
 
     if rank != 0:
         if dist is not None:
@@ -193,6 +185,15 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         cpu, v_distinct = cpu_baseline(stream, cfg, args.cpu_seconds, n_frames)
 
+    # HBM bytes per launch from the PMC passes of profiles/collect_traffic.sh (rocprofv3 cannot wrap this process from
+    # inside); null when no measurement of this configuration is committed
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+    if os.path.exists(tpath):
+        for kname, v in json.load(open(tpath)).items():
+            for short in ("integrate", "raycast"):
+                if ("k_" + short) in kname:
+                    traffic[short] = v["hbm_bytes_per_launch"]
     P = W * H
     roof = {}
     for name in ("integrate", "raycast"):
@@ -206,7 +207,7 @@ def main():
             alg = 24.0 * P + 4.0 * (v_distinct if v_distinct else 0.0)            # 24*P + 4*V
         gbs = alg / avg_s / 1e9
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n,
                       "algorithmic_bytes_per_launch": round(alg)}
     dominant = max(roof, key=lambda k: prof[k][0]) if roof else None
     out = {

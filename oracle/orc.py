@@ -58,6 +58,17 @@ def lib(omp: bool = False):
         "orc_check_pose": (i, [fp, fp, fp, u, u, f]),
         "orc_solve6": (None, [fp, C.POINTER(C.c_double)]),
         "orc_se3_exp": (None, [C.POINTER(C.c_double), fp]),
+        "orc_h_fminf": (f, [f, f]),
+        "orc_h_fmaxf": (f, [f, f]),
+        "orc_h_clampf": (f, [f, f, f]),
+        "orc_h_border_clamp": (i, [i, i, i]),
+        "orc_h_clamp_int": (i, [i, i, i]),
+        "orc_h_dot3": (f, [fp, fp]),
+        "orc_h_cross3": (None, [fp, fp, fp]),
+        "orc_h_length3": (f, [fp]),
+        "orc_h_normalize3": (None, [fp, fp]),
+        "orc_h_floor_frac": (None, [f, fp, fp, C.POINTER(C.c_int)]),
+        "orc_h_constants": (None, [fp]),
         "orc_inverse": (None, [fp, fp]),
         "orc_matmul": (None, [fp, fp, fp]),
         "orc_integrate": (None, [sp, u3, f3, fp, u, u, fp, fp, f, f, cp]),

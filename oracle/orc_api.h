@@ -30,6 +30,17 @@ int orc_update_pose(float *pose16, const float *output, float icp_threshold);
 int orc_check_pose(float *pose16, const float *oldPose16, const float *output, unsigned W, unsigned H, float track_threshold);
 void orc_solve6(const float *vals27, double *x6);
 void orc_se3_exp(const double *mu6, float *out16);
+float orc_h_fminf(float a, float b);
+float orc_h_fmaxf(float a, float b);
+float orc_h_clampf(float f, float a, float b);
+int orc_h_border_clamp(int x, int i, int size);
+int orc_h_clamp_int(int v, int lo, int hi);
+float orc_h_dot3(const float *a, const float *b);
+void orc_h_cross3(const float *a, const float *b, float *o);
+float orc_h_length3(const float *a);
+void orc_h_normalize3(const float *a, float *o);
+void orc_h_floor_frac(float v, float *fl, float *fr, int *as_int);
+void orc_h_constants(float *out12);
 void orc_inverse(const float *in16, float *out16);
 void orc_matmul(const float *a16, const float *b16, float *out16);
 void orc_integrate(short *vol, const unsigned size[3], const float dim[3], const float *depth, unsigned W, unsigned H,

@@ -405,6 +405,25 @@ int orc_check_pose(float *pose16, const float *oldPose16, const float *output, u
 }
 
 void orc_solve6(const float *vals27, double *x6) { solve6(vals27, x6); }
+
+// Scalar / vector helpers exported one by one so that tests/test_oracle_golden.py can hold them against the
+// vectors produced by the reference's own cutil_math.h (oracle/_ref/cutil_probe).
+float orc_h_fminf(float a, float b) { return fmin_h(a, b); }
+float orc_h_fmaxf(float a, float b) { return fmax_h(a, b); }
+float orc_h_clampf(float f, float a, float b) { return clamp_h(f, a, b); }
+int orc_h_border_clamp(int x, int i, int size) { return imax(0, imin(x + i, size - 1)); }   // the index rule of orc_bilateral_filter
+int orc_h_clamp_int(int v, int lo, int hi) { return imax(lo, imin(v, hi)); }
+float orc_h_dot3(const float *a, const float *b) { return dot3(mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2])); }
+void orc_h_cross3(const float *a, const float *b, float *o) { const f3 c = cross3(mk3(a[0], a[1], a[2]), mk3(b[0], b[1], b[2])); o[0] = c.x; o[1] = c.y; o[2] = c.z; }
+float orc_h_length3(const float *a) { return length3(mk3(a[0], a[1], a[2])); }
+void orc_h_normalize3(const float *a, float *o) { const f3 c = normalize3(mk3(a[0], a[1], a[2])); o[0] = c.x; o[1] = c.y; o[2] = c.z; }
+void orc_h_floor_frac(float v, float *fl, float *fr, int *as_int) { const float f = floorf(v); *fl = f; *fr = v - f; *as_int = (int)v; }
+void orc_h_constants(float *out12) {
+    // e_delta, dist_threshold, normal_threshold, track_threshold, maxweight, nearPlane, farPlane, delta are
+    // duplicated in orc_pipeline.cpp; the values used by the kernels' callers come from there
+    extern const float orc_constants_table[12];
+    for (int i = 0; i < 12; ++i) out12[i] = orc_constants_table[i];
+}
 void orc_se3_exp(const double *mu6, float *out16) { const M4 m = se3_exp_to_m4(mu6); std::memcpy(out16, &m, sizeof m); }
 void orc_inverse(const float *in16, float *out16) { const M4 m = inverse(load_m4(in16)); std::memcpy(out16, &m, sizeof m); }
 void orc_matmul(const float *a16, const float *b16, float *out16) { const M4 m = matmul(load_m4(a16), load_m4(b16)); std::memcpy(out16, &m, sizeof m); }

@@ -28,6 +28,11 @@ const float light[3] = {1, 1, -1.0};
 const float ambient[3] = {(float)0.1, (float)0.1, (float)0.1};
 }  // namespace
 
+// for tests/test_oracle_golden.py: e_delta, dist_threshold, normal_threshold, track_threshold, maxweight, nearPlane,
+// farPlane, delta, light xyz, ambient (x)
+extern "C" const float orc_constants_table[12] = {e_delta, dist_threshold, normal_threshold, track_threshold, maxweight, nearPlane,
+                                                   farPlane, delta, light[0], light[1], light[2], ambient[0]};
+
 struct orc_kfusion {
     unsigned W, H;
     unsigned volRes[3];

@@ -20,7 +20,7 @@ BENCH_BIN = os.path.join(HERE, "kfusion-benchmark-hip")
 
 HIP_SOURCES = ["kf_kernels.hip", "kf_pipeline.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wno-unused-result"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def hipcc() -> str:
