@@ -31,6 +31,9 @@ struct DevState {
     unsigned long long solve_fallbacks;     // ICP solves that needed the Jacobi path (ill-conditioned J^T J)
 };
 
+// state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran
+struct IcpState { M4 pose; int done[KFH_MAX_LEVELS]; int executed; int pad[3]; };
+
 struct FrameLogEntry { M4 pose; int tracked; int integrated; int frame; int pad; };
 
 // bits of k_control's op mask, executed in this order by one thread
@@ -56,6 +59,7 @@ struct ControlArgs {
 namespace launch {
 unsigned track_blocks(unsigned w, unsigned h);
 unsigned track_blocks_max();
+unsigned icp_blocks(unsigned w, unsigned h);
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
                 const Gauss5 &g, float e_d, hipStream_t s);
@@ -75,6 +79,13 @@ void reduce_trackdata(float *partials, const kfh_track_data *J, unsigned JW, uns
 void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, int level, float icp_threshold,
            int do_solve, hipStream_t s);
 void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s);
+// fused ICP iteration: solve of the previous iteration in the prologue, association + partial sums in the body
+void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
+              int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
+              unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
+              float icp_threshold, float dist_threshold, float normal_threshold, hipStream_t s);
+void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
+               int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);
 void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s);
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,

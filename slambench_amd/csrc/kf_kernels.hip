@@ -191,9 +191,10 @@ __device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, cons
     r.error = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.J[i] = 0.f;
+    // both input maps are fetched before the first test so the two loads are in flight together
     const float4 n4 = inN[px + py * inW];
-    if (n4.x == kInvalid) { r.result = -1; return r; }
     const float4 v4 = inV[px + py * inW];
+    if (n4.x == kInvalid) { r.result = -1; return r; }
     const f3 pv = xform(T, mk3(v4.x, v4.y, v4.z));
     unsigned rx = 0, ry = 0;
     if (have_reference) {
@@ -203,8 +204,8 @@ __device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, cons
         rx = (unsigned)u; ry = (unsigned)w;
     }
     const float4 rn4 = refN[rx + ry * refW];
+    const float4 rv4 = refV[rx + ry * refW];   // same pixel as the normal: gather both at once
     if (rn4.x == kInvalid) { r.result = -3; return r; }
-    const float4 rv4 = refV[rx + ry * refW];
     const f3 n_ref = mk3(rn4.x, rn4.y, rn4.z);
     const f3 diff = sub3(mk3(rv4.x, rv4.y, rv4.z), pv);
     const f3 pn = rotate(T, mk3(n4.x, n4.y, n4.z));
@@ -251,8 +252,9 @@ __device__ __forceinline__ void halve(const float (&in)[2 * N], float (&out)[N],
     }
 }
 
+template <int NT>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__restrict__ partial) {
-    __shared__ float sm[TR_THREADS / 64][32];
+    __shared__ float sm[NT / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a16[16], a8[8], a4[4], a2[2], a1[1];
     halve<16>(acc, a16, lane & 32, 32);
@@ -267,7 +269,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__re
     if (threadIdx.x < 32) {
         float t = sm[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < TR_THREADS / 64; ++w) t += sm[w][threadIdx.x];
+        for (int w = 1; w < NT / 64; ++w) t += sm[w][threadIdx.x];
         partial[threadIdx.x] = t;
     }
 }
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_track_reduce(
         }
         accumulate(acc, r.result, r.error, r.J);
     }
-    if (partials) block_reduce_store(acc, partials + (size_t)blockIdx.x * 32);
+    if (partials) block_reduce_store<TR_THREADS>(acc, partials + (size_t)blockIdx.x * 32);
 }
 
 // reduceKernel on an existing TrackData map (kernel-level API; the pipeline uses the fused kernel)
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_reduce_trackdata(float *__restri
         const kfh_track_data row = J[px + py * JW];
         accumulate(acc, row.result, row.error, row.J);
     }
-    block_reduce_store(acc, partials + (size_t)blockIdx.x * 32);
+    block_reduce_store<TR_THREADS>(acc, partials + (size_t)blockIdx.x * 32);
 }
 
 // =====================================================================================
@@ -405,8 +407,7 @@ __global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction
 // Control kernel: the scalar glue of Kfusion::tracking / integration / raycasting (cpp:924-1004) run by one
 // thread on the device, so frame gating and pose algebra need no host round trip.
 // =====================================================================================
-__global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, ControlArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, const ControlArgs &a) {
     const bool track_frame = (a.frame % a.tracking_rate) == 0;   // cpp:927
     if (ops & OP_TRACK_BEGIN) {
         for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
@@ -459,6 +460,130 @@ __global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__
         const M4 vp = a.use_view_pose ? a.view_pose : st->pose;
         st->render.view = matmul(vp, inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]));
         st->render.enabled = 1;
+    }
+}
+
+__global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, ControlArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    control_ops(st, log, ops, a);
+}
+
+// =====================================================================================
+// Fused ICP iteration.  The reference loop (cpp:950-967) is track -> reduce -> host solve -> next track.  Here one
+// launch per iteration does:   [prologue] add up the partial sums the PREVIOUS iteration left, solve the 6x6 system,
+// update the pose and the level-converged flag;   [body] associate this level's pixels with that pose and leave new
+// partial sums.  Every block runs the prologue redundantly on the same inputs (same instruction stream, same bits),
+// so no block waits for another one and the launch boundary is the only synchronisation; block 0 records the state
+// the next launch starts from.  Compared with separate track / solve launches this removes one dependent launch per
+// iteration and the second early-exit launch of every skipped iteration.
+// =====================================================================================
+constexpr int ICP_THREADS = 1024;   // 16 waves: a wide block adds up the previous partials quickly and keeps their count low
+
+struct IcpShared {
+    M4 pose;
+    int done[KFH_MAX_LEVELS];
+    int prev_executed;
+    int executed;
+    float red[32];
+    float sm[ICP_THREADS / 32][33];
+};
+
+// Brings `sh` to the state entering iteration `it`: pose and flags after the update of iteration it-1.
+__device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *__restrict__ iters,
+                                            const float *__restrict__ partials_prev, int it, int prev_level,
+                                            unsigned prev_nblocks, float icp_threshold, bool writer) {
+    if (threadIdx.x == 0) {
+        if (it == 0) {
+            sh.pose = st->pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = st->level_done[l];
+            sh.prev_executed = 0;
+        } else {
+            const IcpState prev = iters[it - 1];
+            sh.pose = prev.pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = prev.done[l];
+            sh.prev_executed = prev.executed;
+        }
+    }
+    __syncthreads();
+    if (!sh.prev_executed) return;   // uniform: the previous iteration was skipped, nothing to solve
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    constexpr int G = ICP_THREADS / 32;
+    float acc = 0.f;
+    for (unsigned b = g; b < prev_nblocks; b += G) acc += partials_prev[(size_t)b * 32 + c];
+    sh.sm[g][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v = sh.sm[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < G; ++k) v += sh.sm[k][threadIdx.x];
+        sh.red[threadIdx.x] = v;
+        if (writer) st->reduction[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        M4 pose = sh.pose;
+        bool fast = true;
+        const bool converged = apply_update(pose, sh.red, icp_threshold, fast);
+        sh.pose = pose;
+        if (converged) sh.done[prev_level] = 1;
+        if (writer) {
+            st->icp_iterations += 1;
+            if (!fast) st->solve_fallbacks += 1;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ICP_THREADS) void k_icp_iter(
+    DevState *__restrict__ st, IcpState *__restrict__ iters, const float *__restrict__ partials_prev,
+    float *__restrict__ partials_out, int *__restrict__ result_map, int it, int level, int prev_level,
+    unsigned prev_nblocks, const float4 *__restrict__ inV, const float4 *__restrict__ inN, unsigned inW, unsigned inH,
+    const float4 *__restrict__ refV, const float4 *__restrict__ refN, unsigned refW, unsigned refH, float icp_threshold,
+    float dist_threshold, float normal_threshold) {
+    __shared__ IcpShared sh;
+    const bool writer = blockIdx.x == 0;
+    icp_advance(sh, st, iters, partials_prev, it, prev_level, prev_nblocks, icp_threshold, writer);
+    if (threadIdx.x == 0) {
+        sh.executed = sh.done[level] ? 0 : 1;
+        if (writer) {
+            IcpState &o = iters[it];
+            o.pose = sh.pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+            o.executed = sh.executed;
+        }
+    }
+    __syncthreads();
+    if (!sh.executed) return;
+    const M4 T = sh.pose;
+    const M4 view = st->track.view;
+    const int have_reference = st->track.have_reference;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    const unsigned n = inW * inH;
+    for (unsigned p = blockIdx.x * ICP_THREADS + threadIdx.x; p < n; p += gridDim.x * ICP_THREADS) {
+        const unsigned py = p / inW, px = p - py * inW;
+        const PixelTrack r = track_pixel(px, py, inV, inN, inW, refV, refN, refW, refH, T, view, have_reference,
+                                         dist_threshold, normal_threshold);
+        result_map[px + py * refW] = r.result;   // full-resolution row stride on every level (cpp:512)
+        accumulate(acc, r.result, r.error, r.J);
+    }
+    block_reduce_store<ICP_THREADS>(acc, partials_out + (size_t)blockIdx.x * 32);
+}
+
+// Closes the loop: the update of the last iteration, then the scalar glue that follows tracking (checkPose, integrate
+// gate, raycast pose, frame log) — one launch instead of a solve and a control launch.
+__global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict__ st, FrameLogEntry *__restrict__ log,
+                                                          const IcpState *__restrict__ iters,
+                                                          const float *__restrict__ partials_prev, int n_iters,
+                                                          int prev_level, unsigned prev_nblocks, float icp_threshold,
+                                                          int ops, ControlArgs a) {
+    __shared__ IcpShared sh;
+    icp_advance(sh, st, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, true);
+    if (threadIdx.x == 0) {
+        st->pose = sh.pose;
+        for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = sh.done[l];
+        control_ops(st, log, ops, a);
     }
 }
 
@@ -830,6 +955,13 @@ unsigned track_blocks(unsigned w, unsigned h) {
 
 unsigned track_blocks_max() { return TR_MAX_BLOCKS; }
 
+unsigned icp_blocks(unsigned w, unsigned h) {
+    // default 256 blocks of 1024 threads (one per CU, ~1.2 pixels per thread at 640x480); KFH_ICP_BLOCKS overrides
+    static const long cap_env = [] { const char *e = getenv("KFH_ICP_BLOCKS"); const long v = e ? atol(e) : 0; return (v >= 1 && v <= (long)TR_MAX_BLOCKS) ? v : 256L; }();
+    const unsigned n = (w * h + ICP_THREADS - 1) / ICP_THREADS;
+    return n < 1 ? 1 : (n > (unsigned)cap_env ? (unsigned)cap_env : n);
+}
+
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
     const size_t n = (size_t)sx * sy * sz;
     k_init_volume<<<2048, 256, 0, s>>>(reinterpret_cast<uint32_t *>(vol), n);
@@ -888,6 +1020,20 @@ void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, 
 
 void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s) {
     k_control<<<1, 64, 0, s>>>(st, log, ops, a);
+}
+
+void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
+              int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
+              unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
+              float icp_threshold, float dist_threshold, float normal_threshold, hipStream_t s) {
+    k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(st, iters, partials_prev, partials_out, result_map, it, level, prev_level,
+                                              prev_nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold,
+                                              dist_threshold, normal_threshold);
+}
+
+void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
+               int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s) {
+    k_icp_final<<<1, ICP_THREADS, 0, s>>>(st, log, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, ops, a);
 }
 
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s) {

@@ -60,7 +60,9 @@ struct kfh_context {
     std::vector<float4 *> d_inV, d_inN;
     float4 *d_vertex = nullptr, *d_normal = nullptr;
     int *d_result = nullptr;
-    float *d_partials = nullptr;
+    float *d_partials = nullptr;      // two buffers of track_blocks_max() x 32, alternating by ICP iteration
+    IcpState *d_icp = nullptr;        // one entry per ICP iteration of a frame
+    int icp_total = 0;
     int16_t *d_volume = nullptr;
     DevState *d_state = nullptr;
     FrameLogEntry *d_log = nullptr;
@@ -157,11 +159,14 @@ static int enqueue_preprocess(kfh_context *c, const uint16_t *d_in, unsigned inW
     return 1;
 }
 
-static void enqueue_tracking(kfh_context *c, const float k[4], float icp_threshold, unsigned tracking_rate, unsigned frame) {
+// Queues the pyramid and the whole ICP loop.  `end_ops` are the control operations that follow tracking; they ride on
+// the launch that applies the last ICP update (or on a plain control launch when this frame is not tracked).
+static void enqueue_tracking(kfh_context *c, const float k[4], float icp_threshold, unsigned tracking_rate, unsigned frame,
+                             int end_ops, unsigned integration_rate) {
     ControlArgs a;
-    fill_control(c, a, k, frame, tracking_rate, 1);
+    fill_control(c, a, k, frame, tracking_rate, integration_rate);
     if (frame % a.tracking_rate != 0) {   // cpp:927-928: nothing runs, not even the pyramid
-        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
+        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN | end_ops, a, c->stream);
         return;
     }
     const int L = (int)c->iterations.size();
@@ -179,16 +184,21 @@ static void enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     prof_end(c, KFH_PROF_PYRAMID);
     prof_begin(c, KFH_PROF_ICP);
     launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
+    float *part[2] = {c->d_partials, c->d_partials + (size_t)launch::track_blocks_max() * 32};
+    int it = 0, prev_level = 0;
+    unsigned prev_nb = 0;
     for (int level = L - 1; level >= 0; --level) {   // cpp:950-967
         const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
-        const unsigned nb = launch::track_blocks(w, h);
+        const unsigned nb = launch::icp_blocks(w, h);
         for (int i = 0; i < c->iterations[level]; ++i) {
-            launch::track_reduce(c->d_partials, c->d_result, nullptr, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex,
-                                 c->d_normal, c->W, c->H, &c->d_state->pose, &c->d_state->track,
-                                 &c->d_state->level_done[level], dist_threshold, normal_threshold, c->stream);
-            launch::solve(c->d_state, nullptr, c->d_partials, nb, level, icp_threshold, 1, c->stream);
+            launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
+                             nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
+                             dist_threshold, normal_threshold, c->stream);
+            prev_level = level; prev_nb = nb; ++it;
         }
     }
+    if (it > 0) launch::icp_final(c->d_state, c->d_log, c->d_icp, part[(it + 1) & 1], it, prev_level, prev_nb, icp_threshold, end_ops, a, c->stream);
+    else launch::control(c->d_state, c->d_log, end_ops, a, c->stream);
     prof_end(c, KFH_PROF_ICP);
 }
 
@@ -269,7 +279,10 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_vertex, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_normal, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_result, P * sizeof(int)));
-    ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)launch::track_blocks_max() * 32 * sizeof(float)));
+    ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float)));
+    c->icp_total = 0;
+    for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
+    ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
     ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
     ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
     ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
@@ -333,7 +346,7 @@ void kfh_destroy(kfh_context *c) {
     for (float *p : c->d_scaled) hipFree(p);
     for (float4 *p : c->d_inV) hipFree(p);
     for (float4 *p : c->d_inN) hipFree(p);
-    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_volume);
+    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume);
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
     for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
@@ -372,10 +385,7 @@ int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, ui
 
 int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame) {
     if (!c || !k || !tracking_rate) return KFH_ERR_ARGUMENT;
-    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame);
-    ControlArgs a;
-    fill_control(c, a, k, frame, tracking_rate, 1);
-    launch::control(c->d_state, c->d_log, OP_TRACK_END, a, c->stream);
+    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END, 1);
     c->mirror_stale = true;
     refresh_mirror(c);
     return c->h_state->tracked;
@@ -409,10 +419,8 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
     if (depth_is_device) r = kfh_preprocessing_device(c, depth_mm, in_width, in_height);
     else r = kfh_preprocessing(c, depth_mm, in_width, in_height);
     if (r < 0) return r;
-    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame);
-    ControlArgs a;
-    fill_control(c, a, k, frame, tracking_rate, integration_rate);
-    launch::control(c->d_state, c->d_log, OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
+    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END,
+                     integration_rate);
     // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the
     // integrate gate (tracking verdict) is the device flag the kernel reads
     if ((frame % integration_rate) == 0 || frame <= 3) enqueue_integrate(c, mu);
