@@ -134,6 +134,8 @@ inline f3 grad(const Vol &v, f3 pos) {
     return scale3(mul3(g, cell), 0.5f * kShort2Float);
 }
 
+static thread_local int g_ray_samples = 0;   // instrumentation: interp() calls of the last cast_ray
+
 // cpp:674-725
 inline f4 cast_ray(const Vol &v, unsigned px, unsigned py, const M4 &view, float nearPlane, float farPlane,
                    float step, float largestep) {
@@ -151,10 +153,12 @@ inline f4 cast_ray(const Vol &v, unsigned px, unsigned py, const M4 &view, float
     f4 miss = {0.f, 0.f, 0.f, 0.f};
     if (tnear < tfar) {
         float t = tnear, stepsize = largestep;
+        g_ray_samples = 1;
         float f_t = interp(v, add3(origin, scale3(dir, t)));
         float f_tt = 0;
         if (f_t > 0) {
             for (; t < tfar; t += stepsize) {
+                ++g_ray_samples;
                 f_tt = interp(v, add3(origin, scale3(dir, t)));
                 if (f_tt < 0) break;
                 if (f_tt < 0.8f) stepsize = step;
@@ -497,6 +501,19 @@ void orc_raycast(float *vertex, float *normal, unsigned W, unsigned H, const sho
         for (size_t i = 0; i < touched.size(); ++i) n += touched[i];
         cnt->raycast_distinct_voxels = n;
     }
+}
+
+// instrumentation only: number of interp() samples each ray of a raycast takes (same march as orc_raycast)
+void orc_raycast_samples(int *samples, unsigned W, unsigned H, const short *vol, const unsigned size[3], const float dim[3],
+                         const float *view16, float nearPlane, float farPlane, float step, float largestep) {
+    Vol v = make_vol(const_cast<short *>(vol), size, dim, nullptr);
+    const M4 view = load_m4(view16);
+    for (unsigned y = 0; y < H; ++y)
+        for (unsigned x = 0; x < W; ++x) {
+            g_ray_samples = 0;
+            cast_ray(v, x, y, view, nearPlane, farPlane, step, largestep);
+            samples[x + y * W] = g_ray_samples;
+        }
 }
 
 // cpp:814-842

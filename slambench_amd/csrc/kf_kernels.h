@@ -89,14 +89,17 @@ void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const fl
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);
 void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s);
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
-               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, hipStream_t s);
+               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
+               hipStream_t s);
+size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz);
+void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             hipStream_t s);
+             const unsigned char *skip_flags, hipStream_t s);
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s);
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
-                   hipStream_t s);
+                   const unsigned char *skip_flags, hipStream_t s);
 }  // namespace launch
 }  // namespace kf

@@ -600,11 +600,15 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
 // The voxel read is issued for every voxel that projects into the image (it is needed unless the depth is
 // 0 or the voxel lies more than mu behind the surface); traffic stays within a few MB of 8*U + 4*P.
 // =====================================================================================
+constexpr short kSkipShortFwd = 26600;
+__device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z);
+
 template <int IB>
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
-                                                   unsigned zchunk, unsigned long long *__restrict__ updated_total) {
+                                                   unsigned zchunk, unsigned long long *__restrict__ updated_total,
+                                                   unsigned char *__restrict__ skip_flags) {
     if (!ip->enabled) return;
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     unsigned updated = 0;
@@ -656,7 +660,10 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                     float tsdf = c[i].x * kShort2Float, w = c[i].y;
                     tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
                     w = fmin_h(w + 1, maxweight);
-                    cell[(size_t)i * plane] = make_short2((short)(tsdf * 32766.0f), (short)w);
+                    const short ts = (short)(tsdf * 32766.0f);
+                    cell[(size_t)i * plane] = make_short2(ts, (short)w);
+                    if (skip_flags && ts < kSkipShortFwd)
+                        mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
                     ++updated;
                 }
             }
@@ -776,8 +783,52 @@ __device__ __forceinline__ f3 grad(const VolView &v, f3 pos) {
     return scale3(mul3(g, cell), 0.5f * kShort2Float);
 }
 
-__device__ __forceinline__ float4 cast_ray(const VolView &v, unsigned px, unsigned py, const M4 &view, float nearPlane,
-                                           float farPlane, float step, float largestep) {
+// ---- exact empty-space skipping -------------------------------------------------------------------------
+// One byte per 8x8x8 brick, set by integrate when it stores a TSDF below kSkipShort (0.8118) into any voxel of the
+// brick dilated by (-1, +9) voxels per axis.  A march sample whose (approximately located) base voxel lies in an
+// unmarked brick has all eight trilinear taps >= kSkipShort, hence a value >= 0.81 > 0.8: the reference loop
+// (cpp:709-716) would neither break nor shorten its step there, and the value itself is only needed if the very next
+// sample is negative - in which case it is evaluated after the fact.  The march therefore takes exactly the steps the
+// CPU takes and returns the same bits, but most free-space samples cost a flag lookup instead of 150 instructions and
+// four gathers.  The +-1 dilation absorbs the rounding difference between pos*size/dim (exact path) and pos*(size/dim).
+constexpr short kSkipShort = kSkipShortFwd;
+
+struct SkipGrid {
+    const unsigned char *flags;   // nullptr = no skipping
+    int nbx, nby, nbz;
+    float kx, ky, kz;             // size / dim per axis
+    int two_phase;                // loop shape (only with flags)
+};
+
+__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const VolView &v, f3 pos) {
+    const int vx = (int)floorf(pos.x * g.kx - 0.5f), vy = (int)floorf(pos.y * g.ky - 0.5f), vz = (int)floorf(pos.z * g.kz - 0.5f);
+    const int bx = imin(imax(vx, 0), v.sx - 1) >> 3, by = imin(imax(vy, 0), v.sy - 1) >> 3, bz = imin(imax(vz, 0), v.sz - 1) >> 3;
+    return g.flags[bx + g.nbx * (by + g.nby * bz)] == 0;
+}
+
+__device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z) {
+    const int x0 = x >= 2 ? (x - 2) >> 3 : 0, x1 = imin((x + 1) >> 3, nbx - 1);
+    const int y0 = y >= 2 ? (y - 2) >> 3 : 0, y1 = imin((y + 1) >> 3, nby - 1);
+    const int z0 = z >= 2 ? (z - 2) >> 3 : 0, z1 = imin((z + 1) >> 3, nbz - 1);
+    for (int bz = z0; bz <= z1; ++bz)
+        for (int by = y0; by <= y1; ++by)
+            for (int bx = x0; bx <= x1; ++bx) flags[bx + nbx * (by + nby * bz)] = 1;
+}
+
+// full rebuild (after reset or when a volume is injected from the host)
+__global__ __launch_bounds__(256) void k_build_skip_grid(unsigned char *__restrict__ flags, const short2 *__restrict__ vol,
+                                                         unsigned sx, unsigned sy, unsigned sz, int nbx, int nby, int nbz) {
+    const size_t n = (size_t)sx * sy * sz;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (vol[i].x < kSkipShort) {
+            const unsigned x = i % sx, y = (i / sx) % sy, z = i / ((size_t)sx * sy);
+            mark_bricks(flags, nbx, nby, nbz, x, y, z);
+        }
+    }
+}
+
+__device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py, const M4 &view,
+                                           float nearPlane, float farPlane, float step, float largestep) {
     const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
     const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
     const f3 invR = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -791,16 +842,44 @@ __device__ __forceinline__ float4 cast_ray(const VolView &v, unsigned px, unsign
     const float tfar = fmin_h(smallest_tmax, farPlane);
     if (tnear < tfar) {
         float t = tnear, stepsize = largestep;
-        float f_t = interp(v, add3(origin, scale3(dir, t)));
+        const f3 p0 = add3(origin, scale3(dir, t));
+        // `lazy`: the last accepted sample (f_t) lies in an empty brick; it is known to be >= 0.81 but not evaluated
+        bool lazy = sg.flags && brick_is_empty(sg, v, p0);
+        float t_ft = t;
+        float f_t = lazy ? 1.0f : interp(v, p0);
         float f_tt = 0;
         if (f_t > 0) {
-            for (; t < tfar; t += stepsize) {
-                f_tt = interp(v, add3(origin, scale3(dir, t)));
-                if (f_tt < 0) break;
-                if (f_tt < 0.8f) stepsize = step;
-                f_t = f_tt;
+            if (sg.two_phase) {
+                // Same visiting order as `for (; t < tfar; t += stepsize)`, written as two phases so that the lanes of
+                // a wave first run through their free-space samples in a short loop and then take the expensive
+                // sample together.
+                while (true) {
+                    while (t < tfar && brick_is_empty(sg, v, add3(origin, scale3(dir, t)))) {
+                        lazy = true;
+                        t_ft = t;
+                        t += stepsize;
+                    }
+                    if (!(t < tfar)) break;
+                    f_tt = interp(v, add3(origin, scale3(dir, t)));
+                    if (f_tt < 0) break;
+                    if (f_tt < 0.8f) stepsize = step;
+                    f_t = f_tt;
+                    lazy = false;
+                    t += stepsize;
+                }
+            } else {
+                for (; t < tfar; t += stepsize) {
+                    const f3 p = add3(origin, scale3(dir, t));
+                    if (sg.flags && brick_is_empty(sg, v, p)) { lazy = true; t_ft = t; continue; }
+                    f_tt = interp(v, p);
+                    if (f_tt < 0) break;
+                    if (f_tt < 0.8f) stepsize = step;
+                    f_t = f_tt;
+                    lazy = false;
+                }
             }
             if (f_tt < 0) {
+                if (lazy) f_t = interp(v, add3(origin, scale3(dir, t_ft)));
                 t = t + stepsize * f_tt / (f_t - f_tt);
                 const f3 p = add3(origin, scale3(dir, t));
                 return make_float4(p.x, p.y, p.z, t);
@@ -810,27 +889,131 @@ __device__ __forceinline__ float4 cast_ray(const VolView &v, unsigned px, unsign
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Pixel mapping shared by raycast and renderVolume: a 256-thread block covers 16x16 pixels, each wave an
-// 8x8 screen tile, so the 64 rays of a wave walk neighbouring voxels (gather locality in L1/L2).
+// ---- group-cooperative ray march --------------------------------------------------------------------------
+// The kernel time of the one-ray-per-lane march is the longest ray's serial chain (measured: mean 36 samples per
+// ray, longest tile 136; 0.8 us per dependent sample => ~110 us, with most SIMDs idle after ~35 us).  Here Q
+// adjacent lanes march ONE ray together: the sample times of a round are t, t+s, t+2s, ... (each lane adds the step q
+// times, so the float sequence is the serial one), the Q samples are evaluated in parallel, and the first lane at which
+// the reference loop would do something other than "continue" (leave the volume, cross zero, or switch from the large to
+// the small step, cpp:709-716) decides the ray's next state.  Samples past that lane are discarded.  The chain per ray
+// shrinks Q-fold and the frame exposes Q times more waves; decisions and bits are those of the serial loop.
+template <int Q>
+__device__ __forceinline__ float4 cast_ray_group(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py,
+                                                 const M4 &view, float nearPlane, float farPlane, float step,
+                                                 float largestep) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane & (Q - 1), base = lane & ~(Q - 1);
+    const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
+    const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
+    const f3 invR = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const f3 tbot = mul3(scale3(invR, -1.0f), origin);
+    const f3 ttop = mul3(invR, sub3(v.dim, origin));
+    const f3 tmin = mk3(fmin_h(ttop.x, tbot.x), fmin_h(ttop.y, tbot.y), fmin_h(ttop.z, tbot.z));
+    const f3 tmax = mk3(fmax_h(ttop.x, tbot.x), fmax_h(ttop.y, tbot.y), fmax_h(ttop.z, tbot.z));
+    const float largest_tmin = fmax_h(fmax_h(tmin.x, tmin.y), fmax_h(tmin.x, tmin.z));
+    const float smallest_tmax = fmin_h(fmin_h(tmax.x, tmax.y), fmin_h(tmax.x, tmax.z));
+    const float tnear = fmax_h(largest_tmin, nearPlane);
+    const float tfar = fmin_h(smallest_tmax, farPlane);
+    const float4 miss = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(tnear < tfar)) return miss;
+    float t = tnear, stepsize = largestep;
+    bool small = false;          // stepsize has been switched to `step`
+    bool lazy = false;           // f_t lies in an empty brick: >= 0.81, value not evaluated
+    float f_t = 0.f, t_ft = t;
+    bool first = true;
+    while (true) {
+        float tq = t;
+#pragma unroll
+        for (int i = 0; i < Q - 1; ++i) tq = (i < q) ? tq + stepsize : tq;
+        const bool in_range = tq < tfar;
+        bool s_lazy = false;
+        float f = 0.f;
+        if (in_range) {
+            const f3 p = add3(origin, scale3(dir, tq));
+            if (sg.flags && brick_is_empty(sg, v, p)) s_lazy = true;
+            else f = interp(v, p);
+        }
+        // what the serial loop does at this sample: 0 continue, 1 out of range, 2 zero crossing, 3 large->small step
+        int kind = 0;
+        if (!in_range) kind = 1;
+        else if (!s_lazy && f < 0) kind = 2;
+        else if (!s_lazy && !small && f < 0.8f) kind = 3;
+        const unsigned long long ball = __ballot(kind != 0);
+        const unsigned evmask = (unsigned)((ball >> base) & ((1ull << Q) - 1ull));
+        if (first) {
+            // cpp:706-708: the march only starts if the sample at tnear (lane 0 of this round) is positive
+            first = false;
+            const float f0 = __shfl(f, base, 64);
+            const int lazy0 = __shfl((int)s_lazy, base, 64);
+            const int in0 = __shfl((int)in_range, base, 64);
+            if (in0 && !lazy0 && !(f0 > 0)) return miss;
+        }
+        if (evmask == 0) {   // all Q samples are plain "continue": f_t <- last of them, t <- its time + stepsize
+            f_t = __shfl(f, base + Q - 1, 64);
+            lazy = __shfl((int)s_lazy, base + Q - 1, 64) != 0;
+            t_ft = __shfl(tq, base + Q - 1, 64);
+            t = t_ft + stepsize;
+            continue;
+        }
+        const int e = __ffs(evmask) - 1;
+        if (e > 0) {
+            f_t = __shfl(f, base + e - 1, 64);
+            lazy = __shfl((int)s_lazy, base + e - 1, 64) != 0;
+            t_ft = __shfl(tq, base + e - 1, 64);
+        }
+        const int ekind = __shfl(kind, base + e, 64);
+        const float te = __shfl(tq, base + e, 64), fe = __shfl(f, base + e, 64);
+        if (ekind == 1) return miss;                 // left the volume / far plane without a crossing
+        if (ekind == 2) {                            // cpp:717-720
+            if (lazy) f_t = interp(v, add3(origin, scale3(dir, t_ft)));
+            const float th = te + stepsize * fe / (f_t - fe);
+            const f3 p = add3(origin, scale3(dir, th));
+            return make_float4(p.x, p.y, p.z, th);
+        }
+        // cpp:713-715: first sample below 0.8 -> switch to the small step from here on
+        small = true;
+        stepsize = step;
+        f_t = fe;
+        lazy = false;
+        t = te + stepsize;
+    }
+}
+
+// Pixel mapping shared by raycast and renderVolume.  A wave marches 64/Q rays laid out as a small screen tile (8x8, 8x4,
+// 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a 256-thread block is 2x2 such tiles.
+template <int Q>
 __device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y) {
+    constexpr int R = 64 / Q;                         // rays per wave
+    constexpr int RW = (Q == 1 || Q == 2) ? 8 : 4;    // tile width
+    constexpr int RH = R / RW;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const unsigned r = lane / Q;
+    x = (blockIdx.x * 2 + (wave & 1)) * RW + (r % RW);
+    y = (blockIdx.y * 2 + (wave >> 1)) * RH + (r / RW);
+}
+
+template <int Q>
+__device__ __forceinline__ float4 march(const VolView &v, const SkipGrid &sg, unsigned x, unsigned y, const M4 &view,
+                                        float nearPlane, float farPlane, float step, float largestep) {
+    if (Q == 1) return cast_ray(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
+    return cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
 }
 
 // raycastKernel (cpp:726-757)
+template <int Q>
 __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal, unsigned W,
                                                  unsigned H, const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                  unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
-                                                 float farPlane, float step, float largestep) {
+                                                 float farPlane, float step, float largestep, SkipGrid sg) {
     if (!rp->enabled) return;
     unsigned x, y;
-    tile_pixel(x, y);
-    if (x >= W || y >= H) return;
+    tile_pixel<Q>(x, y);
+    if (x >= W || y >= H) return;     // uniform per ray group: all Q lanes share the pixel
     const M4 view = rp->view;
     VolView v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
-    const float4 hit = cast_ray(v, x, y, view, nearPlane, farPlane, step, largestep);
+    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
+    if ((threadIdx.x & (Q - 1)) != 0) return;   // one lane of the group finishes the pixel
     const unsigned p = x + y * W;
     if (hit.w > 0.0) {
         vertex[p] = make_float4(hit.x, hit.y, hit.z, 0.f);
@@ -848,18 +1031,20 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
 }
 
 // renderVolumeKernel (cpp:880-913)
+template <int Q>
 __global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
                                                        const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                        unsigned sz, f3 dim, const RayParams *__restrict__ rp,
                                                        float nearPlane, float farPlane, float step, float largestep,
-                                                       f3 light, f3 ambient) {
+                                                       f3 light, f3 ambient, SkipGrid sg) {
     unsigned x, y;
-    tile_pixel(x, y);
+    tile_pixel<Q>(x, y);
     if (x >= W || y >= H) return;
     const M4 view = rp->view;
     VolView v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
-    const float4 hit = cast_ray(v, x, y, view, nearPlane, farPlane, step, largestep);
+    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
+    if ((threadIdx.x & (Q - 1)) != 0) return;
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (hit.w > 0) {
         const f3 test = mk3(hit.x, hit.y, hit.z);
@@ -1044,6 +1229,34 @@ void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned 
     k_check_pose<<<1, 64, 0, s>>>(pose, oldPose, reduction32, W, H, thr, ok);
 }
 
+static long env_long(const char *name, long lo, long hi, long dflt);
+
+static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned sy, unsigned sz, f3 dim) {
+    SkipGrid g;
+    g.flags = flags;
+    g.nbx = (sx + 7) >> 3; g.nby = (sy + 7) >> 3; g.nbz = (sz + 7) >> 3;
+    g.kx = sx / dim.x; g.ky = sy / dim.y; g.kz = sz / dim.z;
+    static const long tp = env_long("KFH_RAY_TWO_PHASE", 0, 1, 0);
+    g.two_phase = (flags && tp) ? 1 : 0;
+    return g;
+}
+
+size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz) { return (size_t)((sx + 7) >> 3) * ((sy + 7) >> 3) * ((sz + 7) >> 3); }
+
+void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
+    hipMemsetAsync(flags, 0, skip_grid_bytes(sx, sy, sz), s);
+    k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3);
+}
+
+static int ray_group() {   // lanes per ray (KFH_RAY_GROUP = 1, 2, 4, 8)
+    static const long g = env_long("KFH_RAY_GROUP", 1, 8, 4);
+    return (g == 1 || g == 2 || g == 8) ? (int)g : 4;
+}
+static dim3 ray_grid(int q, unsigned W, unsigned H) {
+    const unsigned rw = (q <= 2) ? 8 : 4, rh = (64 / q) / rw;
+    return dim3((W + 2 * rw - 1) / (2 * rw), (H + 2 * rh - 1) / (2 * rh));
+}
+
 static long env_long(const char *name, long lo, long hi, long dflt) {
     const char *e = getenv(name);
     if (!e) return dflt;
@@ -1052,7 +1265,8 @@ static long env_long(const char *name, long lo, long hi, long dflt) {
 }
 
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
-               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, hipStream_t s) {
+               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
+               hipStream_t s) {
     // enough z-chunks to put >= ~8192 waves in flight on 256 CUs; each chunk replays its z0 additions
     static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 8, 8);
@@ -1064,17 +1278,22 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
     const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);
-    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
-    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
-    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total);
+    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
+    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
+    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
 }
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             hipStream_t s) {
-    const dim3 grid((W + 15) / 16, (H + 15) / 16);
-    k_raycast<<<grid, 256, 0, s>>>(vertex, normal, W, H, reinterpret_cast<const short2 *>(vol), sx, sy, sz, dim, p,
-                                   nearPlane, farPlane, step, largestep);
+             const unsigned char *skip_flags, hipStream_t s) {
+    const short2 *vv = reinterpret_cast<const short2 *>(vol);
+    const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
+    switch (ray_group()) {
+    case 1: k_raycast<1><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
+    case 2: k_raycast<2><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
+    case 8: k_raycast<8><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
+    default: k_raycast<4><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
+    }
 }
 
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {
@@ -1087,10 +1306,15 @@ void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hi
 
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
-                   hipStream_t s) {
-    const dim3 grid((W + 15) / 16, (H + 15) / 16);
-    k_render_volume<<<grid, 256, 0, s>>>(out, W, H, reinterpret_cast<const short2 *>(vol), sx, sy, sz, dim, p, nearPlane,
-                                         farPlane, step, largestep, light, ambient);
+                   const unsigned char *skip_flags, hipStream_t s) {
+    const short2 *vv = reinterpret_cast<const short2 *>(vol);
+    const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
+    switch (ray_group()) {
+    case 1: k_render_volume<1><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
+    case 2: k_render_volume<2><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
+    case 8: k_render_volume<8><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
+    default: k_render_volume<4><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
+    }
 }
 
 }  // namespace launch

@@ -64,6 +64,8 @@ struct kfh_context {
     IcpState *d_icp = nullptr;        // one entry per ICP iteration of a frame
     int icp_total = 0;
     int16_t *d_volume = nullptr;
+    unsigned char *d_skip = nullptr;   // one byte per 8^3 brick: set once a TSDF below 0.81 was stored near it
+    bool use_skip = true;
     DevState *d_state = nullptr;
     FrameLogEntry *d_log = nullptr;
     unsigned log_capacity = 8192;
@@ -205,14 +207,14 @@ static void enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
 static void enqueue_integrate(kfh_context *c, float mu) {
     prof_begin(c, KFH_PROF_INTEGRATE);
     launch::integrate(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim, c->d_floatDepth, c->W, c->H,
-                      &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->stream);
+                      &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->use_skip ? c->d_skip : nullptr, c->stream);
     prof_end(c, KFH_PROF_INTEGRATE);
 }
 
 static void enqueue_raycast(kfh_context *c, float mu) {
     prof_begin(c, KFH_PROF_RAYCAST);
     launch::raycast(c->d_vertex, c->d_normal, c->W, c->H, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
-                    &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->stream);
+                    &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->stream);
     prof_end(c, KFH_PROF_RAYCAST);
 }
 
@@ -284,6 +286,8 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
     ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
     ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
+    ok &= HIP_TRY(hipMalloc(&c->d_skip, launch::skip_grid_bytes(res[0], res[1], res[2])));
+    { const char *e = getenv("KFH_NO_SKIP"); c->use_skip = !(e && e[0] == '1'); }
     ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
     ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
     for (int i = 0; i < 3; ++i) {
@@ -346,7 +350,7 @@ void kfh_destroy(kfh_context *c) {
     for (float *p : c->d_scaled) hipFree(p);
     for (float4 *p : c->d_inV) hipFree(p);
     for (float4 *p : c->d_inN) hipFree(p);
-    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume);
+    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip);
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
     for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
@@ -358,6 +362,7 @@ void kfh_destroy(kfh_context *c) {
 
 void kfh_reset(kfh_context *c) {
     launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
+    HIP_TRY(hipMemsetAsync(c->d_skip, 0, launch::skip_grid_bytes(c->volRes[0], c->volRes[1], c->volRes[2]), c->stream));
 }
 
 void kfh_synchronise(kfh_context *c) {
@@ -458,7 +463,8 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
     launch::control(c->d_state, c->d_log, OP_RENDER_BEGIN, a, c->stream);
     const f3 light = mk3(1, 1, -1.0), ambient = mk3((float)0.1, (float)0.1, (float)0.1);   // constant_parameters.h:25-26
     launch::render_volume(c->d_render[2], w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
-                          &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient, c->stream);
+                          &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient,
+                          c->use_skip ? c->d_skip : nullptr, c->stream);
     queue_readback(c, 2, out, w, h);
 }
 
@@ -574,6 +580,8 @@ int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, 
     if (!c || !name || !host_in || !find_buffer(c, name, &p, &b) || nbytes != b) return KFH_ERR_ARGUMENT;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!HIP_TRY(hipMemcpy(p, host_in, b, hipMemcpyHostToDevice))) return KFH_ERR_HIP;
+    if (std::string(name) == "volume")   // an injected volume invalidates the brick flags: rebuild them from scratch
+        launch::build_skip_grid(c->d_skip, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     c->mirror_stale = true;
     return (int64_t)b;
 }
@@ -744,7 +752,7 @@ void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], c
     std::memset(&hp, 0, sizeof hp);
     hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
     HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
-    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, s);
+    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 
@@ -766,7 +774,7 @@ void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const
     RayParams *d = upload_ray(view16, s);
     if (!d) return;
     launch::raycast(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), w, h, vol, size[0], size[1], size[2],
-                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, s);
+                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 
@@ -787,7 +795,7 @@ void kfh_k_render_volume(uint8_t *out, uint32_t w, uint32_t h, const int16_t *vo
     if (!d) return;
     launch::render_volume(reinterpret_cast<uchar4 *>(out), w, h, vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), d,
                           near_plane, far_plane, step, largestep, mk3(light[0], light[1], light[2]),
-                          mk3(ambient[0], ambient[1], ambient[2]), s);
+                          mk3(ambient[0], ambient[1], ambient[2]), nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 
