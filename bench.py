@@ -38,7 +38,7 @@ CONFIGS = {
     "cfg3": (640, 480, 512, (10, 5, 4), 1, 1),        # configs[2]: HBM-bound integrate+raycast stress
     "cfg4": (1280, 960, 512, (10, 5, 4, 4), 2, 4),    # configs[3]: 4-level ICP
 }
-MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, 1e-5, 1
+MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, float(os.environ.get("KFH_DEBUG_ICP_THRESHOLD", "1e-5")), 1
 
 
 def parse():
@@ -76,7 +76,7 @@ def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_
         step(f)
     kf.synchronise()
     if not with_renders:
-        kf.set_profiling(["integrate", "raycast"])
+        kf.set_profiling(["icp", "integrate", "raycast"])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -220,6 +220,7 @@ def main():
                    "frames_per_gpu": args.steps, "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks},
         "fps_total": None if fps_total is None else round(fps_total, 2),
         "ate_m": ate,
+        "phase_us": {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items() if v[1]},
         "roofline": roof.get(dominant),
         "roofline_other": {k: v for k, v in roof.items() if k != dominant},
         "cpu_baseline": cpu,

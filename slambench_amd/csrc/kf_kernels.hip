@@ -523,7 +523,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     if (threadIdx.x == 0) {
         M4 pose = sh.pose;
         bool fast = true;
-        const bool converged = apply_update(pose, sh.red, icp_threshold, fast);
+        const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast);   // < 0: timing probe
         sh.pose = pose;
         if (converged) sh.done[prev_level] = 1;
         if (writer) {
