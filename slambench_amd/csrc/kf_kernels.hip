@@ -592,23 +592,45 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
 // a full 256-byte line of the x-fastest short2 grid.  The camera-space position is carried along z by
 // repeated addition exactly like the CPU loop (cpp:645-646); a thread that starts at z0 > 0 first replays
 // the z0 additions in registers so that its float state carries the bits of the serial march.
+// The six running sums are kept as three float pairs and advanced with packed adds (v_pk_add_f32).
 //
-// The z march is processed in batches of IB voxels: first the geometry of the whole batch (the four
-// reject tests need no memory), then all depth gathers and voxel reads of the batch are issued together,
-// then the updates.  A column therefore has up to 2*IB loads in flight instead of two dependent round
-// trips per voxel, which is what bounded the first version (64 us at 256^3 = 64 z-steps x ~1 us).
-// The voxel read is issued for every voxel that projects into the image (it is needed unless the depth is
-// 0 or the voxel lies more than mu behind the surface); traffic stays within a few MB of 8*U + 4*P.
+// Most voxels do not project into the image, and the kernel is instruction bound, not byte bound, so the work per
+// rejected voxel is what matters.  The z march is cut into batches of IB voxels:
+//   * batch reject: x/z and y/z are monotonic along the column while z stays positive, so if BOTH end voxels of a batch
+//     are outside the image on the same side with a 0.1-pixel margin (tested with multiplications), or both are behind
+//     the camera, every voxel of the batch fails cpp:647-653 and only the IB packed additions are spent on it;
+//   * otherwise each voxel runs the reference tests, with the two IEEE divisions of the projection skipped for voxels
+//     that the same multiplication test already puts outside;
+//   * the depth gathers of a batch are issued together, then the voxel reads of the survivors;
+//   * t = depth - cam.z decides cheaply what the reference computes through diff = t * sqrt(1 + (x/z)^2 + (y/z)^2):
+//     since that factor is >= 1, t <= -mu means diff <= -mu (skip, no voxel access) and t >= mu means
+//     diff / mu >= 1, i.e. sdf == 1.0f exactly; only the band |t| < mu needs the two divisions and the square root.
+// Every decision and every stored short is the one the CPU loop produces.
 // =====================================================================================
 constexpr short kSkipShortFwd = 26600;
 __device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z);
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct ColumnState { v2f a, b, c; };   // (pos.x, pos.y), (pos.z, cam.x), (cam.y, cam.z)
+
+// conservative "projects outside the image on this side" bits; valid only where cam.z > 0.
+// lo = -(0.5 + margin), wlim/hlim = size - 0.5 + margin:  x/z < lo => x/z + 0.5 < 0;  x/z > wlim => x/z + 0.5 > W - 1.
+__device__ __forceinline__ unsigned outside_bits(float camx, float camy, float camz, float lo, float wlim, float hlim) {
+    unsigned m = 0;
+    m |= (camx < lo * camz) ? 1u : 0u;
+    m |= (camx > wlim * camz) ? 2u : 0u;
+    m |= (camy < lo * camz) ? 4u : 0u;
+    m |= (camy > hlim * camz) ? 8u : 0u;
+    return m;
+}
 
 template <int IB>
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
                                                    unsigned zchunk, unsigned long long *__restrict__ updated_total,
-                                                   unsigned char *__restrict__ skip_flags) {
+                                                   unsigned char *__restrict__ skip_flags, int dbg) {
     if (!ip->enabled) return;
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     unsigned updated = 0;
@@ -616,56 +638,125 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         const M4 invTrack = ip->invTrack, K = ip->K;
         const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
         const f3 cameraDelta = rotate(K, delta);
-        f3 pos = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
-        f3 cam = xform(K, pos);
+        const f3 pos0 = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
+        const f3 cam0 = xform(K, pos0);
+        ColumnState S;
+        S.a = (v2f){pos0.x, pos0.y}; S.b = (v2f){pos0.z, cam0.x}; S.c = (v2f){cam0.y, cam0.z};
+        const v2f da = (v2f){delta.x, delta.y}, db = (v2f){delta.z, cameraDelta.x}, dc = (v2f){cameraDelta.y, cameraDelta.z};
         const unsigned z0 = blockIdx.z * zchunk;
         const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
-        for (unsigned z = 0; z < z0; ++z) { pos = add3(pos, delta); cam = add3(cam, cameraDelta); }
+        for (unsigned z = 0; z < z0; ++z) { S.a += da; S.b += db; S.c += dc; }
         const size_t plane = (size_t)sx * sy;
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+        // per-voxel test: the very floats the reference divides, 0.1 px of margin covers the rounding of the product.
+        // batch test: interior voxels are the endpoints' interpolation plus at most IB roundings of the running sums
+        // (<= 4e-3 for |cam.x| < 1e4); with cam.z > 0.05 that moves x/z by < 0.08, hence a 0.25 px margin.
+        const float wlim = (float)W - 0.4f, hlim = (float)H - 0.4f;
+        const float wlim_b = (float)W - 0.25f, hlim_b = (float)H - 0.25f;
+        const float ptol = 2e-6f * (float)(W > H ? W : H);
         for (unsigned zb = z0; zb < z1; zb += IB, cell += (size_t)IB * plane) {
-            unsigned live = 0;            // bit i: voxel zb+i projects into the image
-            unsigned pix[IB];
-            float camz[IB], fac[IB];
+            const unsigned nb = (z1 - zb) < (unsigned)IB ? (z1 - zb) : (unsigned)IB;
+            const ColumnState first = S;
+            ColumnState last;
+            // advance over the batch; `last` is the state of its final voxel, S the state of the next batch's first
+            if (nb == (unsigned)IB) {   // whole batch (all but possibly the last of a chunk): straight-line packed adds
 #pragma unroll
-            for (int i = 0; i < IB; ++i) {
-                if (zb + i < z1) {
-                    if (!(pos.z < 0.0001f)) {                                   // cpp:647
-                        const float px = cam.x / cam.z + 0.5f, py = cam.y / cam.z + 0.5f;
-                        if (!(px < 0 || px > wm1 || py < 0 || py > hm1)) {      // cpp:651-653
-                            live |= 1u << i;
-                            pix[i] = (unsigned)px + (unsigned)py * W;
-                            camz[i] = cam.z;
-                            fac[i] = sqrtf(1 + sq(pos.x / pos.z) + sq(pos.y / pos.z));
-                        }
-                    }
-                    pos = add3(pos, delta);
-                    cam = add3(cam, cameraDelta);
+                for (int i = 0; i < IB - 1; ++i) { S.a += da; S.b += db; S.c += dc; }
+                last = S;
+                S.a += da; S.b += db; S.c += dc;
+            } else {
+                last = S;
+                for (unsigned i = 0; i < nb; ++i) {
+                    last = S;
+                    S.a += da; S.b += db; S.c += dc;
                 }
             }
-            if (!live) continue;
+            {
+                const float z_f = first.b.x, z_l = last.b.x;          // pos.z
+                const float cz_f = first.c.y, cz_l = last.c.y;        // cam.z
+                const bool behind = z_f < 0.00005f && z_l < 0.00005f;
+                bool outside = false;
+                if (cz_f > 0.05f && cz_l > 0.05f)
+                    outside = (outside_bits(first.b.y, first.c.x, cz_f, -0.75f, wlim_b, hlim_b) &
+                               outside_bits(last.b.y, last.c.x, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
+                if (behind || outside || (dbg & 1)) continue;   // dbg: timing probes only (KFH_INTEGRATE_DBG)
+            }
+            // detailed pass over the batch, replaying the additions from its first voxel
+            ColumnState T = first;
+            unsigned live = 0;            // bit i: voxel zb+i projects into the image
+            unsigned pix[IB];
+            float px_[IB], py_[IB], pz_[IB], camz[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                if ((unsigned)i < nb) {
+                    const float posz = T.b.x, cx = T.b.y, cy = T.c.x, cz = T.c.y;
+                    if (!(posz < 0.0001f)) {                                       // cpp:647
+                        const bool far_out = cz > 0.f && outside_bits(cx, cy, cz, -0.6f, wlim, hlim) != 0u;
+                        if (!far_out) {
+                            // cpp:649-654 needs only the comparisons with 0 / W-1 / H-1 and the integer part of
+                            // fl(fl(c/z) + 0.5).  c * rcp(z) is within 3 ulp of fl(c/z), i.e. within 3.6e-7 * max(W,H)
+                            // pixels wherever those outcomes are undecided; unless it lands within `ptol` (5x that) of
+                            // an integer it gives the same decisions and the same integer.  The IEEE divisions run
+                            // only for those rare pixels.
+                            const float rz = __builtin_amdgcn_rcpf(cz);
+                            float px = cx * rz + 0.5f, py = cy * rz + 0.5f;
+                            const float nx = rintf(px), ny = rintf(py);
+                            if (fabsf(px - nx) < ptol || fabsf(py - ny) < ptol || !(fabsf(px) < 65536.f) || !(fabsf(py) < 65536.f)) {
+                                px = cx / cz + 0.5f;
+                                py = cy / cz + 0.5f;
+                            }
+                            if (!(px < 0 || px > wm1 || py < 0 || py > hm1)) {     // cpp:651-653
+                                live |= 1u << i;
+                                pix[i] = (unsigned)px + (unsigned)py * W;
+                                px_[i] = T.a.x; py_[i] = T.a.y; pz_[i] = posz; camz[i] = cz;
+                            }
+                        }
+                    }
+                    T.a += da; T.b += db; T.c += dc;
+                }
+            }
+            if (!live || (dbg & 2)) continue;
             float d[IB];
-            short2 c[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
-                if (live & (1u << i)) { d[i] = depth[pix[i]]; c[i] = cell[(size_t)i * plane]; }
+                if (live & (1u << i)) d[i] = depth[pix[i]];
+            // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
+            unsigned need = 0;
+            float t_[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 if (!(live & (1u << i))) continue;
-                if (d[i] == 0) continue;                                        // cpp:655
-                const float diff = (d[i] - camz[i]) * fac[i];
-                if (diff > -mu) {
-                    const float sdf = fmin_h(1.f, diff / mu);
-                    float tsdf = c[i].x * kShort2Float, w = c[i].y;
-                    tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
-                    w = fmin_h(w + 1, maxweight);
-                    const short ts = (short)(tsdf * 32766.0f);
-                    cell[(size_t)i * plane] = make_short2(ts, (short)w);
-                    if (skip_flags && ts < kSkipShortFwd)
-                        mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
-                    ++updated;
+                if (d[i] == 0) continue;                                           // cpp:655
+                const float t = d[i] - camz[i];
+                if (t <= -mu) continue;
+                t_[i] = t;
+                need |= 1u << i;
+            }
+            if (!need || (dbg & 4)) continue;
+            short2 c[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                if (!(need & (1u << i))) continue;
+                float sdf;
+                if (t_[i] >= mu) {
+                    sdf = 1.f;
+                } else {
+                    const float diff = t_[i] * sqrtf(1 + sq(px_[i] / pz_[i]) + sq(py_[i] / pz_[i]));
+                    if (!(diff > -mu)) continue;
+                    sdf = fmin_h(1.f, diff / mu);
                 }
+                float tsdf = c[i].x * kShort2Float, w = c[i].y;
+                tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
+                w = fmin_h(w + 1, maxweight);
+                const short ts = (short)(tsdf * 32766.0f);
+                cell[(size_t)i * plane] = make_short2(ts, (short)w);
+                if (skip_flags && ts < kSkipShortFwd && c[i].x >= kSkipShortFwd)   // flags are sticky: first crossing only
+                    mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
+                ++updated;
             }
         }
     }
@@ -1270,6 +1361,7 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     // enough z-chunks to put >= ~8192 waves in flight on 256 CUs; each chunk replays its z0 additions
     static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 8, 8);
+    static const int dbg = (int)env_long("KFH_INTEGRATE_DBG", 0, 7, 0);
     const unsigned waves_xy = ((sx + 63) / 64) * sy;
     unsigned nchunks = chunks_env ? (unsigned)chunks_env : (8192 + waves_xy - 1) / waves_xy;
     if (nchunks < 1) nchunks = 1;
@@ -1278,9 +1370,9 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
     const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);
-    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
-    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
-    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags);
+    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
+    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
+    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
 }
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
