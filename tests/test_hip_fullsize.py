@@ -1,0 +1,160 @@
+"""Parity at BASELINE.json's full sizes (640x480 depth, 256^3 and 512^3 volumes).
+
+The OpenMP twin of the oracle (bit-identical to the serial one, tests/test_oracle_cpu.py) makes a direct comparison
+affordable for a handful of frames; on top of that come size-independent properties: run-to-run determinism, the
+queued computeFrame path against the phase calls, ray-march variants (lanes per ray, empty-space skipping) against each
+other, and an integrate -> raycast round trip.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.util import Dev, f32, m16, pad4, same_bits, u32
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+FRAMES = 7
+
+
+@pytest.fixture(scope="module")
+def stream():
+    return util.synth.make_stream(FRAMES, W, H)
+
+
+@pytest.fixture(scope="module")
+def kfmod(hip):
+    from slambench_amd import kfusion
+    return kfusion
+
+
+def test_pipeline_256_against_oracle(hip, kfmod, orc, stream):
+    """BASELINE configs[1]: -c 1 -v 256 -y 10,5,4 -r 2.  Free-running GPU vs CPU: flags equal, positions within the
+    north-star tolerance, per-voxel TSDF within 1e-4 except a depth-discontinuity handful (the reference's own
+    CPP-vs-OpenMP floor is 1e-4 of the voxels)."""
+    k = list(stream.k)
+    res = (256, 256, 256)
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, stream.init_pos)
+    o = orc.OracleKfusion((W, H), res, util.VOL_DIM, stream.init_pos, omp=True)
+    for f in range(FRAMES):
+        assert np.abs(g.get_position() - o.get_position()).max() <= 1e-4
+        g.preprocessing(stream.depth_mm[f]); o.preprocessing(stream.depth_mm[f])
+        assert same_bits(g.buffer("floatDepth"), o.buffer("floatDepth"))
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        assert g.integration(k, 2, util.MU, f) == o.integration(k, 2, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+    assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
+    vg, vo = g.buffer("volume"), o.buffer("volume")
+    diff = np.abs(vg[..., 0].astype(np.float32) - vo[..., 0].astype(np.float32)) / 32766.0
+    assert float(np.mean(diff > 1e-4)) <= 1e-4, "fraction of voxels off by more than 1e-4: %g" % float(np.mean(diff > 1e-4))
+    assert np.array_equal(vg[..., 1], vo[..., 1]) or float(np.mean(vg[..., 1] != vo[..., 1])) <= 1e-4
+    assert g.get_tracked() and o.counters()["icp_iterations"] > 0
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("res", [256, 512])
+def test_integrate_and_raycast_kernels_full_size(hip, orc, stream, res):
+    """One integrate and one raycast launch at full size on identical inputs: bit-exact TSDF, vertex and normal maps."""
+    dev = Dev()
+    size = (res,) * 3
+    depth = orc.mm2meters(stream.depth_mm[0], W, H, omp=True)
+    pose = stream.poses[0].astype(np.float32)
+    K = orc.camera_matrix(stream.k)
+    inv_track = orc.inverse(pose)
+    vol = orc.init_volume(size, omp=True)
+    d_vol = dev.put(vol)
+    for _ in range(2):
+        orc.integrate(vol, util.VOL_DIM, depth, inv_track, K, omp=True)
+        hip.kfh_k_integrate(d_vol.data_ptr(), u32(size), f32(util.VOL_DIM), dev.put(depth).data_ptr(), W, H, m16(inv_track), m16(K),
+                            0.1, 100.0, dev.stream)
+    got = dev.get(d_vol)
+    assert np.array_equal(got, vol)
+    assert (vol[..., 1] > 0).mean() > 0.03                       # the launch really updated a few percent of the volume
+    view = orc.matmul(pose, orc.inverse_camera_matrix(stream.k))
+    step = float(np.float32(4.8) / np.float32(res))
+    v_ref, n_ref = orc.raycast(vol, util.VOL_DIM, view, W, H, step=step, omp=True)
+    dv, dn = dev.empty((H, W, 4), np.float32), dev.empty((H, W, 4), np.float32)
+    hip.kfh_k_raycast(dv.data_ptr(), dn.data_ptr(), W, H, d_vol.data_ptr(), u32(size), f32(util.VOL_DIM), m16(view), 0.4, 4.0, step,
+                      0.075, dev.stream)
+    assert same_bits(dev.get(dv)[..., :3], v_ref)
+    assert same_bits(dev.get(dn)[..., :3], n_ref)
+    # round trip: the surface seen from the integrating pose sits at the measured depth (frame 0 has identity rotation)
+    hit = n_ref[..., 0] != -2
+    assert hit.mean() > 0.8
+    assert np.abs((v_ref[..., 2] - pose[2, 3])[hit] - depth[hit]).mean() < 4.8 / res
+    dev.clear()
+
+
+def test_compute_frame_is_deterministic_and_equals_phases(hip, kfmod, stream):
+    k = list(stream.k)
+    res = (256, 256, 256)
+    runs = []
+    for mode in ("queued", "queued", "phases"):
+        g = kfmod.Kfusion((W, H), res, util.VOL_DIM, stream.init_pos)
+        for f in range(FRAMES):
+            if mode == "queued":
+                g.compute_frame(stream.depth_mm[f], (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+            else:
+                g.preprocessing(stream.depth_mm[f]); g.tracking(k, util.ICP_THRESHOLD, 1, f)
+                g.integration(k, 2, util.MU, f); g.raycasting(k, util.MU, f)
+        g.synchronise()
+        runs.append((g.get_pose(), g.buffer("volume"), g.buffer("vertex"), g.buffer("normal"), g.render_volume(0, 1, k, 0.075)))
+        g.close()
+    for other in runs[1:]:
+        assert same_bits(runs[0][0], other[0])                     # fixed reduction tree: bitwise reproducible
+        assert np.array_equal(runs[0][1], other[1])
+        assert same_bits(runs[0][2], other[2]) and same_bits(runs[0][3], other[3])
+        assert np.array_equal(runs[0][4], other[4])
+
+
+SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from slambench_amd import kfusion, synth
+s = synth.make_stream(6, 640, 480)
+g = kfusion.Kfusion((640, 480), (256,) * 3, (4.8,) * 3, s.init_pos)
+for f in range(6):
+    g.compute_frame(s.depth_mm[f], (640, 480), list(s.k), 1, 1, 1e-5, 0.1, f)
+g.synchronise()
+np.savez(sys.argv[1], pose=g.get_pose(), vertex=g.buffer("vertex"), normal=g.buffer("normal"), vol=g.buffer("volume")[::4, ::4, ::4],
+         img=g.render_volume(0, 1, list(s.k), 0.075))
+"""
+
+
+def test_ray_march_variants_agree(hip, tmp_path):
+    """Lanes per ray (1, 2, 4, 8) and empty-space skipping on/off are performance knobs only: every variant must
+    reproduce the same bits (each runs in its own process because the knobs are read once per process)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "variant.py"
+    script.write_text(SCRIPT % root)
+    outs = []
+    for env in ({"KFH_RAY_GROUP": "1", "KFH_NO_SKIP": "1"}, {"KFH_RAY_GROUP": "4"}, {"KFH_RAY_GROUP": "8"}, {"KFH_RAY_GROUP": "2", "KFH_NO_SKIP": "1"}):
+        out = str(tmp_path / ("v_%s_%s.npz" % (env.get("KFH_RAY_GROUP"), env.get("KFH_NO_SKIP", "0"))))
+        r = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    for o in outs[1:]:
+        for key in ("pose", "vertex", "normal", "vol", "img"):
+            assert np.array_equal(outs[0][key].view(np.uint8), o[key].view(np.uint8)), key
+
+
+def test_four_level_pyramid(hip, kfmod, orc):
+    """BASELINE configs[3] shape (-y 10,5,4,4) at a size the serial oracle handles quickly."""
+    s = util.synth.make_stream(8, 320, 240)
+    k = list(s.k)
+    pyr = (6, 4, 3, 3)
+    g = kfmod.Kfusion((320, 240), (96, 96, 96), util.VOL_DIM, s.init_pos, pyr)
+    o = orc.OracleKfusion((320, 240), (96, 96, 96), util.VOL_DIM, s.init_pos, pyr, omp=True)
+    for f in range(8):
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        for l in range(4):   # maps of all four levels exist and agree to the bilateral filter's expf tolerance
+            assert np.allclose(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l), rtol=0, atol=2e-5)
+        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+    assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
+    g.close(); o.close()
