@@ -69,6 +69,10 @@ void half_sample(float *out, const float *in, unsigned inW, unsigned inH, float 
 void depth2vertex(float4 *vertex, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s);
 void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H, hipStream_t s);
 void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s);
+// whole input pyramid (half-sampling + vertex/normal maps of every level) in one launch; false if the shape is not
+// covered (more than 4 levels, sizes not divisible by 2^(L-1)) and the per-level kernels must be used
+bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const M4 *invK, unsigned W,
+             unsigned H, float e_d, hipStream_t s);
 // fused ICP pass: per-pixel association + block partial sums.  pose/params/skip are device pointers.
 void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, const float4 *inVertex,
                   const float4 *inNormal, unsigned inW, unsigned inH, const float4 *refVertex, const float4 *refNormal,

@@ -168,6 +168,113 @@ __global__ __launch_bounds__(PBX *PBY) void k_vertex_normal(float4 *__restrict__
 }
 
 // =====================================================================================
+// Whole input pyramid in one launch: halfSampleRobustImage for levels 1..L-1 (cpp:591-626) and depth2vertex +
+// vertex2normal for every level (cpp:200-249), i.e. everything Kfusion::tracking does before the ICP loop
+// (cpp:931-945).  A block owns a 32x32 tile of level 0 and the matching 16x16 / 8x8 / 4x4 tiles of the coarser levels.
+// The filtered depth tile is staged in LDS with a halo wide enough (2^(L-1) pixels) that every coarser depth the
+// block needs - its own tile plus the 1-pixel ring its normals read - can be derived locally, level by level, from
+// LDS; each level's depth tile is written out once and its vertices / normals are computed from the LDS copy with
+// the expressions of the stand-alone kernels, so all maps carry the same bits.  Five dependent launches become one.
+// =====================================================================================
+constexpr int PYR_T = 32;   // level-0 tile edge
+constexpr int PYR_MAX_LEVELS = 4;
+
+struct PyramidArgs {
+    float *scaled[PYR_MAX_LEVELS];      // scaled[0] is the input (bilateral-filtered depth), the others are outputs
+    float4 *vertex[PYR_MAX_LEVELS];
+    float4 *normal[PYR_MAX_LEVELS];
+    M4 invK[PYR_MAX_LEVELS];
+    unsigned W, H;
+    float e_d;
+};
+
+// halo of level l (in level-l pixels): 1 on the coarsest level, doubling towards level 0
+constexpr int pyr_halo(int nlev, int l) { int h = 1; for (int i = nlev - 1; i > l; --i) h *= 2; return h; }
+constexpr int pyr_stride(int nlev, int l) { return (PYR_T >> l) + 2 * pyr_halo(nlev, l); }
+constexpr int pyr_count(int nlev, int l) { return pyr_stride(nlev, l) * pyr_stride(nlev, l); }
+constexpr int pyr_offset(int nlev, int l) { int o = 0; for (int i = 0; i < l; ++i) o += pyr_count(nlev, i); return o; }
+
+template <int NLEV, int L>
+struct PyrGeom {
+    static constexpr int halo = pyr_halo(NLEV, L);
+    static constexpr int tile = PYR_T >> L;
+    static constexpr int stride = pyr_stride(NLEV, L);
+    static constexpr int count = pyr_count(NLEV, L);
+    static constexpr int offset = pyr_offset(NLEV, L);
+};
+
+template <int NLEV, int L>
+__device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, int bx, int by) {
+    using G = PyrGeom<NLEV, L>;
+    const unsigned Wl = a.W >> L, Hl = a.H >> L;
+    const int X0 = (bx * PYR_T) >> L, Y0 = (by * PYR_T) >> L;       // this block's tile origin at level L
+    float *d = lds + G::offset;
+    const int tid = threadIdx.x;
+    if constexpr (L > 0) {
+        // depth of level L over the tile plus its halo, from level L-1 in LDS (robust 2x2 mean, cpp:598-623)
+        using P = PyrGeom<NLEV, L - 1>;
+        const float *dp = lds + P::offset;
+        const int PX0 = ((bx * PYR_T) >> (L - 1)) - P::halo, PY0 = ((by * PYR_T) >> (L - 1)) - P::halo;
+        for (int idx = tid; idx < G::count; idx += blockDim.x) {
+            const int ly = idx / G::stride, lx = idx - ly * G::stride;
+            const int gx = X0 - G::halo + lx, gy = Y0 - G::halo + ly;
+            if (gx < 0 || gy < 0 || gx >= (int)Wl || gy >= (int)Hl) continue;
+            const float *r0 = dp + (2 * gy - PY0) * P::stride + (2 * gx - PX0);
+            const float *r1 = r0 + P::stride;
+            const float v00 = r0[0], v01 = r0[1], v10 = r1[0], v11 = r1[1];
+            const float center = v00;
+            float sum = 0.0f, t = 0.0f;
+            if (fabsf(v00 - center) < a.e_d) { sum += 1.0f; t += v00; }
+            if (fabsf(v01 - center) < a.e_d) { sum += 1.0f; t += v01; }
+            if (fabsf(v10 - center) < a.e_d) { sum += 1.0f; t += v10; }
+            if (fabsf(v11 - center) < a.e_d) { sum += 1.0f; t += v11; }
+            const float r = t / sum;
+            d[idx] = r;
+            if (lx >= G::halo && lx < G::halo + G::tile && ly >= G::halo && ly < G::halo + G::tile)
+                a.scaled[L][gx + (size_t)gy * Wl] = r;      // the tile itself is this block's to publish
+        }
+        __syncthreads();
+    }
+    // vertex and normal maps of the tile (cpp:206-215, 225-247)
+    const M4 invK = a.invK[L];
+    for (int idx = tid; idx < G::tile * G::tile; idx += blockDim.x) {
+        const int ty = idx / G::tile, tx = idx - ty * G::tile;
+        const int x = X0 + tx, y = Y0 + ty;
+        if (x >= (int)Wl || y >= (int)Hl) continue;
+        const int xl = imax(x - 1, 0), xr = imin(x + 1, (int)Wl - 1), yu = imax(y - 1, 0), yd = imin(y + 1, (int)Hl - 1);
+        const int ox = X0 - G::halo, oy = Y0 - G::halo;
+        const f3 c = back_project(d[(y - oy) * G::stride + (x - ox)], x, y, invK);
+        const f3 l = back_project(d[(y - oy) * G::stride + (xl - ox)], xl, y, invK);
+        const f3 r = back_project(d[(y - oy) * G::stride + (xr - ox)], xr, y, invK);
+        const f3 u = back_project(d[(yu - oy) * G::stride + (x - ox)], x, yu, invK);
+        const f3 dn = back_project(d[(yd - oy) * G::stride + (x - ox)], x, yd, invK);
+        a.vertex[L][x + (size_t)y * Wl] = make_float4(c.x, c.y, c.z, 0.f);
+        store_normal(a.normal[L] + x + (size_t)y * Wl, l, r, u, dn);
+    }
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
+    using G0 = PyrGeom<NLEV, 0>;
+    using GL = PyrGeom<NLEV, NLEV - 1>;
+    __shared__ float lds[GL::offset + GL::count];
+    const int bx = blockIdx.x, by = blockIdx.y;
+    // level-0 tile with halo; taps outside the image take the nearest pixel (only the 1-pixel ring is ever read there,
+    // by the clamped neighbour accesses of the normals)
+    const int X0 = bx * PYR_T - G0::halo, Y0 = by * PYR_T - G0::halo;
+    for (int idx = threadIdx.x; idx < G0::count; idx += blockDim.x) {
+        const int ly = idx / G0::stride, lx = idx - ly * G0::stride;
+        const int gx = imax(0, imin(X0 + lx, (int)a.W - 1)), gy = imax(0, imin(Y0 + ly, (int)a.H - 1));
+        lds[idx] = a.scaled[0][gx + (size_t)gy * a.W];
+    }
+    __syncthreads();
+    pyramid_level<NLEV, 0>(a, lds, bx, by);
+    if constexpr (NLEV > 1) pyramid_level<NLEV, 1>(a, lds, bx, by);
+    if constexpr (NLEV > 2) pyramid_level<NLEV, 2>(a, lds, bx, by);
+    if constexpr (NLEV > 3) pyramid_level<NLEV, 3>(a, lds, bx, by);
+}
+
+// =====================================================================================
 // trackKernel (cpp:497-560) + reduceKernel (cpp:251-495), fused.
 // Each thread associates its pixels, accumulates the 32 sums of the reference layout
 //   [0] sum e^2  [1..6] sum e*J  [7..27] upper triangle of J^T J (row-major)
@@ -1274,6 +1381,28 @@ void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H,
 void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
     k_vertex_normal<<<grid, block, 0, s>>>(vertex, normal, depth, W, H, invK);
+}
+
+bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const M4 *invK, unsigned W,
+             unsigned H, float e_d, hipStream_t s) {
+    if (n_levels < 1 || n_levels > PYR_MAX_LEVELS) return false;
+    if (W % (1u << (n_levels - 1)) != 0 || H % (1u << (n_levels - 1)) != 0) return false;   // keep odd sizes on the simple path
+    PyramidArgs a;
+    for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
+        a.scaled[l] = l < n_levels ? scaled[l] : nullptr;
+        a.vertex[l] = l < n_levels ? vertex[l] : nullptr;
+        a.normal[l] = l < n_levels ? normal[l] : nullptr;
+        a.invK[l] = l < n_levels ? invK[l] : identity4();
+    }
+    a.W = W; a.H = H; a.e_d = e_d;
+    const dim3 grid((W + PYR_T - 1) / PYR_T, (H + PYR_T - 1) / PYR_T);
+    switch (n_levels) {
+    case 1: k_pyramid<1><<<grid, 256, 0, s>>>(a); break;
+    case 2: k_pyramid<2><<<grid, 256, 0, s>>>(a); break;
+    case 3: k_pyramid<3><<<grid, 256, 0, s>>>(a); break;
+    default: k_pyramid<4><<<grid, 256, 0, s>>>(a); break;
+    }
+    return true;
 }
 
 void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, const float4 *inVertex,

@@ -173,15 +173,23 @@ static void enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     }
     const int L = (int)c->iterations.size();
     prof_begin(c, KFH_PROF_PYRAMID);
-    for (int i = 1; i < L; ++i)   // cpp:931-935
-        launch::half_sample(c->d_scaled[i], c->d_scaled[i - 1], level_dim(c->W, i - 1), level_dim(c->H, i - 1),
-                            e_delta * 3, c->stream);
-    unsigned lw = c->W, lh = c->H;
-    for (int i = 0; i < L; ++i) {   // cpp:938-945
-        const float s = float(1 << i);
-        const M4 invK = inverse_camera_matrix(k[0] / s, k[1] / s, k[2] / s, k[3] / s);
-        launch::vertex_normal(c->d_inV[i], c->d_inN[i], c->d_scaled[i], lw, lh, invK, c->stream);
-        lw /= 2; lh /= 2;
+    M4 invKs[KFH_MAX_LEVELS];
+    for (int i = 0; i < L; ++i) {   // cpp:940
+        const float sc = float(1 << i);
+        invKs[i] = inverse_camera_matrix(k[0] / sc, k[1] / sc, k[2] / sc, k[3] / sc);
+    }
+    static const bool fused_env = [] { const char *e = getenv("KFH_NO_FUSED_PYRAMID"); return !(e && e[0] == '1'); }();
+    const bool fused = fused_env && launch::pyramid(L, c->d_scaled.data(), c->d_inV.data(), c->d_inN.data(), invKs, c->W, c->H,
+                                                    e_delta * 3, c->stream);
+    if (!fused) {
+        for (int i = 1; i < L; ++i)   // cpp:931-935
+            launch::half_sample(c->d_scaled[i], c->d_scaled[i - 1], level_dim(c->W, i - 1), level_dim(c->H, i - 1),
+                                e_delta * 3, c->stream);
+        unsigned lw = c->W, lh = c->H;
+        for (int i = 0; i < L; ++i) {   // cpp:938-945
+            launch::vertex_normal(c->d_inV[i], c->d_inN[i], c->d_scaled[i], lw, lh, invKs[i], c->stream);
+            lw /= 2; lh /= 2;
+        }
     }
     prof_end(c, KFH_PROF_PYRAMID);
     prof_begin(c, KFH_PROF_ICP);
