@@ -129,7 +129,14 @@ uint64_t kfh_solve_fallbacks(kfh_context *ctx);
 #define KFH_PROF_ICP 2        /* all track+reduce / solve launches of the frame */
 #define KFH_PROF_INTEGRATE 3  /* integrateKernel (one kernel) */
 #define KFH_PROF_RAYCAST 4    /* raycastKernel (one kernel) */
-#define KFH_PROF_COUNT 5
+#define KFH_PROF_RENDER_DEPTH 5
+#define KFH_PROF_RENDER_TRACK 6
+#define KFH_PROF_RENDER_VOLUME 7
+#define KFH_PROF_COUNT 8
+/* With KERNEL_TIMINGS in the environment (the reference's switch, cpp/kernels.cpp:69-70) every phase call prints
+ * "<name> <nanoseconds> <size>" lines on stderr like the reference's TOCK (cpp/kernels.cpp:33-35); fused launches are
+ * reported under bilateralFilterKernel (mm2meters + bilateral), pyramidKernel (half-sampling + vertex/normal maps) and
+ * trackKernel (the whole ICP loop: track + reduce + pose update launches of the frame). */
 void kfh_set_profiling(kfh_context *ctx, uint32_t phase_mask);
 int kfh_read_profile(kfh_context *ctx, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]);
 

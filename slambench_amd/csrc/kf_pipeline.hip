@@ -80,9 +80,10 @@ struct kfh_context {
     // optional HIP-event timing of pipeline phases (kfh_set_profiling)
     unsigned prof_mask = 0;
     std::vector<hipEvent_t> prof_events[KFH_PROF_COUNT];   // start/stop pairs, in issue order
-    size_t prof_used[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
-    double prof_ms[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
-    uint64_t prof_n[KFH_PROF_COUNT] = {0, 0, 0, 0, 0};
+    size_t prof_used[KFH_PROF_COUNT] = {};
+    double prof_ms[KFH_PROF_COUNT] = {};
+    uint64_t prof_n[KFH_PROF_COUNT] = {};
+    bool kernel_timings = false;   // KERNEL_TIMINGS: print name / ns / size per phase like the reference's TOCK
     // host mirror
     bool mirror_stale = false;
     M4 viewPose; bool useViewPose = false;
@@ -105,6 +106,13 @@ static void prof_collect(kfh_context *c) {
             if (hipEventElapsedTime(&ms, c->prof_events[p][i], c->prof_events[p][i + 1]) == hipSuccess) {
                 c->prof_ms[p] += ms;
                 c->prof_n[p] += 1;
+                if (c->kernel_timings) {
+                    static const char *names[KFH_PROF_COUNT] = {"bilateralFilterKernel", "pyramidKernel", "trackKernel", "integrateKernel",
+                                                                "raycastKernel", "renderDepthKernel", "renderTrackKernel", "renderVolumeKernel"};
+                    const unsigned long long size = p == KFH_PROF_INTEGRATE ? (unsigned long long)c->volRes[0] * c->volRes[1]
+                                                                            : (unsigned long long)c->W * c->H;
+                    fprintf(stderr, "%s %llu %llu\n", names[p], (unsigned long long)(ms * 1.0e6), size);
+                }
             }
         }
         c->prof_used[p] = 0;
@@ -315,6 +323,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     HIP_TRY(hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
     c->viewPose = pose;
     kfh_reset(c);
+    if (getenv("KERNEL_TIMINGS")) { c->kernel_timings = true; c->prof_mask = (1u << KFH_PROF_COUNT) - 1u; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return c;
 }
@@ -375,6 +384,7 @@ void kfh_reset(kfh_context *c) {
 
 void kfh_synchronise(kfh_context *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->kernel_timings) prof_collect(c);
     flush_pending(c);
 }
 
@@ -452,13 +462,17 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
 
 void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     if (!c || !out || w != c->W || h != c->H) return;
+    prof_begin(c, KFH_PROF_RENDER_DEPTH);
     launch::render_depth(c->d_render[0], c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
+    prof_end(c, KFH_PROF_RENDER_DEPTH);
     queue_readback(c, 0, out, w, h);
 }
 
 void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     if (!c || !out || w != c->W || h != c->H) return;
+    prof_begin(c, KFH_PROF_RENDER_TRACK);
     launch::render_track(c->d_render[1], c->d_result, w, h, c->stream);
+    prof_end(c, KFH_PROF_RENDER_TRACK);
     queue_readback(c, 1, out, w, h);
 }
 
@@ -470,9 +484,11 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
     fill_control(c, a, k, (unsigned)frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RENDER_BEGIN, a, c->stream);
     const f3 light = mk3(1, 1, -1.0), ambient = mk3((float)0.1, (float)0.1, (float)0.1);   // constant_parameters.h:25-26
+    prof_begin(c, KFH_PROF_RENDER_VOLUME);
     launch::render_volume(c->d_render[2], w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
                           &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient,
                           c->use_skip ? c->d_skip : nullptr, c->stream);
+    prof_end(c, KFH_PROF_RENDER_VOLUME);
     queue_readback(c, 2, out, w, h);
 }
 
@@ -536,7 +552,7 @@ uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh
 
 void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
     prof_collect(c);
-    c->prof_mask = phase_mask;
+    c->prof_mask = c->kernel_timings ? ((1u << KFH_PROF_COUNT) - 1u) : phase_mask;
     for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; }
 }
 

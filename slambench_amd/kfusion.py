@@ -159,7 +159,7 @@ class Kfusion:
     def integrate_updated(self):
         return int(self.L.kfh_integrate_updated(self.h))
 
-    PHASES = ("preprocess", "pyramid", "icp", "integrate", "raycast")
+    PHASES = ("preprocess", "pyramid", "icp", "integrate", "raycast", "render_depth", "render_track", "render_volume")
 
     def set_profiling(self, phases=()):
         mask = 0

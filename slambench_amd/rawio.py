@@ -49,3 +49,41 @@ class RawDepthReader:
 
     def close(self):
         self.f.close()
+
+
+class SceneDepthReader:
+    """ICL-NUIM scene directory reader (python twin of SceneDepthReader, interface.h:99-197): float32 arithmetic,
+    ray length -> z-depth, then metres -> uint16 millimetres by truncation (interface.h:139-149)."""
+
+    WIDTH, HEIGHT = 640, 480
+
+    def __init__(self, directory: str):
+        import os
+        if not os.path.isdir(directory):
+            raise ValueError("No such directory " + directory)
+        self.dir = directory
+        self.frame = -1
+        u, v = np.meshgrid(np.arange(self.WIDTH, dtype=np.float32), np.arange(self.HEIGHT, dtype=np.float32))
+        a = (u - np.float32(319.50)) / np.float32(481.20)
+        b = (v - np.float32(239.50)) / np.float32(-480.00)
+        self.scale = np.sqrt(a * a + b * b + np.float32(1)).astype(np.float32)
+
+    def get_input_size(self):
+        return (self.WIDTH, self.HEIGHT)
+
+    def get_k(self):
+        return (481.20, 480.00, 319.50, 239.50)
+
+    def read_next_depth_frame(self):
+        import os
+        self.frame += 1
+        path = os.path.join(self.dir, "scene_00_%04d.depth" % self.frame)
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            vals = np.array(f.read().split(), dtype=np.float32)
+        buf = np.zeros(self.WIDTH * self.HEIGHT, np.float32)
+        n = min(vals.size, buf.size)
+        buf[:n] = vals[:n]
+        z = buf.reshape(self.HEIGHT, self.WIDTH) / self.scale
+        return (z * np.float32(1000.0)).astype(np.uint16)
