@@ -2,7 +2,7 @@
 
 All calls go through the C ABI (include/kfusion_hip.h, kfh_k_*).  Bars: bit-exact for integer outputs
 (TSDF shorts, result codes, colours) and for every float kernel whose arithmetic is +,-,*,/,sqrt only;
-the bilateral filter is allowed the libm/ocml expf difference (<= 8 ulp, stated below); the ICP
+the bilateral filter restates glibc's expf and is exact as well; the ICP
 reduction re-associates a float sum (relative 2e-5 of the magnitude sum, counters exact).
 """
 import numpy as np
@@ -59,7 +59,7 @@ def test_mm2meters_invalid_ratio(hip, dev):
     assert hip.kfh_k_mm2meters(out.data_ptr(), 5, 10, src.data_ptr(), 10, 10, dev.stream) == -1
 
 
-BILATERAL_ULP = 8  # expf: glibc (CPU) vs ocml (GPU), each < 1 ulp, amplified by the normalised sum t/sum (5 ulp observed)
+BILATERAL_ULP = 0  # the kernel restates glibc's expf algorithm (expf_glibc): bit-identical to the CPU filter
 
 
 @pytest.mark.parametrize("shape", [(120, 160), (37, 53), (8, 8), (1, 5)])

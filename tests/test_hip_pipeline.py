@@ -44,9 +44,7 @@ def test_lockstep_parity(hip, kfmod, orc):
         g.set_pose(o.get_pose())
         g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
         assert same_bits(g.buffer("floatDepth"), o.buffer("floatDepth"))
-        assert util.ulp_diff(g.buffer("scaledDepth0"), o.buffer("scaledDepth0")).max() <= 8
-        # feed the oracle's filtered depth to the GPU so that the rest of the frame is compared on equal inputs
-        g.write_buffer("scaledDepth0", o.buffer("scaledDepth0"))
+        assert same_bits(g.buffer("scaledDepth0"), o.buffer("scaledDepth0"))     # bilateral filter: glibc's expf restated
         tg = g.tracking(k, util.ICP_THRESHOLD, 1, f); to = o.tracking(k, util.ICP_THRESHOLD, 1, f)
         for l in range(3):
             assert same_bits(g.buffer("scaledDepth%d" % l), o.buffer("scaledDepth%d" % l))
