@@ -42,7 +42,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, h) for h in ("kf_math.h", "kf_kernels.h")] + [os.path.join(ROOT, "include", "kfusion_hip.h")]
     if not force and _newer(LIB, deps):
         return LIB
-    cmd = [hipcc()] + HIP_FLAGS + ["-shared", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", LIB]
+    extra = os.environ.get("KFH_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DKFH_ICP_WAVES_PER_SIMD=8)
+    cmd = [hipcc()] + HIP_FLAGS + extra + ["-shared", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

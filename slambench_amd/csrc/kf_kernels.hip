@@ -500,10 +500,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_reduce_trackdata(float *__restri
 //   x = pinv(J^T J) J^T e (double), pose <- exp(x) * pose (float), level done when |x| < icp_threshold.
 // One block; the pose never leaves HBM between ICP iterations.
 // =====================================================================================
-__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold, bool &fast) {
+// `ws`: 72 doubles of LDS for the Jacobi fallback (see solve6_ws)
+__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold, bool &fast, double *ws) {
     double x[6];
     fast = solve6_ldlt(red + 1, x);
-    if (!fast) solve6(red + 1, x);
+    if (!fast) solve6_ws(red + 1, x, reinterpret_cast<double (*)[6]>(ws), reinterpret_cast<double (*)[6]>(ws + 36));
     const M4 delta = se3_exp_to_m4(x);
     pose = matmul(delta, pose);
     double n2 = 0.0;
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(1024) void k_solve(DevState *__restrict__ st, float
     if (st && do_solve && st->level_done[level]) return;
     __shared__ float sm[32][33];
     __shared__ float red[32];
+    __shared__ double jacobi_ws[72];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     float acc = 0.f;
     for (unsigned b = g; b < nblocks; b += 32) acc += partials[(size_t)b * 32 + c];
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(1024) void k_solve(DevState *__restrict__ st, float
     if (threadIdx.x == 0 && st && do_solve) {
         M4 pose = st->pose;
         bool fast = true;
-        const bool converged = apply_update(pose, red, icp_threshold, fast);
+        const bool converged = apply_update(pose, red, icp_threshold, fast, jacobi_ws);
         st->pose = pose;
         st->icp_iterations += 1;
         if (!fast) st->solve_fallbacks += 1;
@@ -544,11 +546,12 @@ __global__ __launch_bounds__(1024) void k_solve(DevState *__restrict__ st, float
 
 __global__ void k_update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double jacobi_ws[72];
     M4 p = *pose;
     float red[32];
     for (int i = 0; i < 32; ++i) red[i] = reduction32[i];
     bool fast;
-    const bool c = apply_update(p, red, icp_threshold, fast);
+    const bool c = apply_update(p, red, icp_threshold, fast, jacobi_ws);
     *pose = p;
     *converged = c ? 1 : 0;
 }
@@ -649,6 +652,10 @@ __global__ void k_control(DevState *__restrict__ st, FrameLogEntry *__restrict__
 // iteration and the second early-exit launch of every skipped iteration.
 // =====================================================================================
 constexpr int ICP_THREADS = 1024;   // 16 waves: a wide block adds up the previous partials quickly and keeps their count low
+#ifndef KFH_ICP_WAVES_PER_SIMD
+#define KFH_ICP_WAVES_PER_SIMD 4
+#endif
+constexpr int ICP_WAVES_PER_SIMD = KFH_ICP_WAVES_PER_SIMD;   // 8 = two blocks per CU (<= 64 VGPRs, the fp64 solve spills)
 
 struct IcpShared {
     M4 pose;
@@ -657,6 +664,7 @@ struct IcpShared {
     int executed;
     float red[32];
     float sm[ICP_THREADS / 32][33];
+    double jacobi_ws[72];
 };
 
 // Brings `sh` to the state entering iteration `it`: pose and flags after the update of iteration it-1.
@@ -694,7 +702,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     if (threadIdx.x == 0) {
         M4 pose = sh.pose;
         bool fast = true;
-        const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast);   // < 0: timing probe
+        const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast, sh.jacobi_ws);   // < 0: timing probe
         sh.pose = pose;
         if (converged) sh.done[prev_level] = 1;
         if (writer) {
@@ -705,7 +713,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     __syncthreads();
 }
 
-__global__ __launch_bounds__(ICP_THREADS) void k_icp_iter(
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(
     DevState *__restrict__ st, IcpState *__restrict__ iters, const float *__restrict__ partials_prev,
     float *__restrict__ partials_out, int *__restrict__ result_map, int it, int level, int prev_level,
     unsigned prev_nblocks, const float4 *__restrict__ inV, const float4 *__restrict__ inN, unsigned inW, unsigned inH,

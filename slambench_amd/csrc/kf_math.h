@@ -173,8 +173,10 @@ KF_HD M4 se3_exp_to_m4(const double mu[6]) {
 // commons.h:380-404: x = pinv(C) b with singular values below max/1e6 dropped; C symmetric 6x6
 // (21 upper-triangle floats, row-major) so the SVD is the eigendecomposition.  Cyclic Jacobi, double.
 // vals = {b[6], C upper triangle[21]}.
-__host__ __device__ inline void solve6(const float *vals, double x[6]) {
-    double C[6][6], Q[6][6], b[6];
+// C and Q are caller-provided 6x6 work arrays: on the device they live in LDS, so that this rarely taken path
+// neither inflates the register allocation of the ICP kernel nor makes it use scratch memory.
+__host__ __device__ inline void solve6_ws(const float *vals, double x[6], double (*C)[6], double (*Q)[6]) {
+    double b[6];
     for (int i = 0; i < 6; ++i) b[i] = vals[i];
     {
         int p = 6;
@@ -225,6 +227,11 @@ __host__ __device__ inline void solve6(const float *vals, double x[6]) {
         const double coef = qb / l;
         for (int k = 0; k < 6; ++k) x[k] += coef * Q[k][i];
     }
+}
+
+__host__ __device__ inline void solve6(const float *vals, double x[6]) {
+    double C[6][6], Q[6][6];
+    solve6_ws(vals, x, C, Q);
 }
 
 // Fast path of the same solve.  When C is comfortably positive definite the pseudo-inverse of
