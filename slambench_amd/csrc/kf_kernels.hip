@@ -957,8 +957,16 @@ struct VolView {
     size_t plane;
 };
 
+// Voxel addressing in 32 bits: the launchers refuse volumes above 2^30 voxels, so the BYTE offset of a voxel fits an
+// unsigned 32-bit register and the load can use the scalar-base + 32-bit vector-offset form (two integer mads per tap
+// instead of two 64-bit multiply-adds).
+__device__ __forceinline__ unsigned voxel_byte_offset(const VolView &v, int x, int y, int z) {
+    return ((unsigned)x + (unsigned)y * (unsigned)v.sx + (unsigned)z * (unsigned)v.plane) * 4u;
+}
+
 __device__ __forceinline__ float tap(const VolView &v, int x, int y, int z) {
-    return (float)v.data[(size_t)x + (size_t)y * v.sx + (size_t)z * v.plane].x;   // commons.h:172-174
+    const short2 *p = reinterpret_cast<const short2 *>(reinterpret_cast<const char *>(v.data) + voxel_byte_offset(v, x, y, z));
+    return (float)p->x;   // commons.h:172-174
 }
 
 struct Taps { int lo[3], up[3]; f3 fr; int base[3]; };
@@ -989,7 +997,7 @@ struct __attribute__((packed, aligned(4))) VoxelPair { int a, b; };
 
 __device__ __forceinline__ void tap_pair(const VolView &v, int p, int y, int z, bool lo_first, bool up_first, float &vlo,
                                          float &vup) {
-    const VoxelPair q = *reinterpret_cast<const VoxelPair *>(v.data + (size_t)p + (size_t)y * v.sx + (size_t)z * v.plane);
+    const VoxelPair q = *reinterpret_cast<const VoxelPair *>(reinterpret_cast<const char *>(v.data) + voxel_byte_offset(v, p, y, z));
     const float first = (float)(short)q.a, second = (float)(short)q.b;   // .x is the low half of each short2
     vlo = lo_first ? first : second;
     vup = up_first ? first : second;
