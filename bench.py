@@ -50,12 +50,15 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total", action="store_true", help="skip the secondary loop with renders")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="HIP-event pairs around icp/integrate/raycast on every n-th timed frame (0 = none; 1 = every "
+                         "frame, which costs ~23 us per frame in queue drains)")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent RGB-D streams processed concurrently on each GPU (throughput mode; the headline is 1)")
     return ap.parse_args()
 
 
-def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_renders, dist, extra_streams=0):
+def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_renders, dist, extra_streams=0, prof_every=8):
     """Warm up on frames [0, n_warm), time frames [n_warm, n_warm + n_steps).  Returns (seconds, kf).
     extra_streams > 0 runs that many more independent contexts (same input stream) interleaved with the first one."""
     W, H, vres, pyramid, irate, zrate = cfg
@@ -83,8 +86,8 @@ def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_
     kf.synchronise()
     for o in others:
         o.synchronise()
-    if not with_renders:
-        kf.set_profiling(["icp", "integrate", "raycast"])
+    if not with_renders and prof_every > 0:
+        kf.set_profiling(["icp", "integrate", "raycast"], every=prof_every)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -164,7 +167,8 @@ def main():
     d_depth = torch.from_numpy(stream.depth_mm.view(np.int16)).cuda()
 
     spg = max(1, args.streams_per_gpu)
-    elapsed, kf = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, False, dist, spg - 1)
+    elapsed, kf = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, False, dist, spg - 1,
+                          args.profile_every)
     prof = kf.read_profile()
     updated = kf.integrate_updated()
     icp_iters = kf.icp_iterations()
@@ -220,7 +224,7 @@ def main():
             alg = 24.0 * P + 4.0 * (v_distinct if v_distinct else 0.0)            # 24*P + 4*V
         gbs = alg / avg_s / 1e9
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n, "sampled_every_n_frames": args.profile_every,
                       "algorithmic_bytes_per_launch": round(alg)}
     dominant = max(roof, key=lambda k: prof[k][0]) if roof else None
     if spg > 1:

@@ -138,6 +138,10 @@ uint64_t kfh_solve_fallbacks(kfh_context *ctx);
  * reported under bilateralFilterKernel (mm2meters + bilateral), pyramidKernel (half-sampling + vertex/normal maps) and
  * trackKernel (the whole ICP loop: track + reduce + pose update launches of the frame). */
 void kfh_set_profiling(kfh_context *ctx, uint32_t phase_mask);
+/* Queued frames (kfh_compute_frame) only: put the event pairs around every n-th frame instead of every frame.  An event
+ * record drains the queue for ~5 us on this GPU (measured: 6 records per frame cost 23 us of a 235 us frame), so a
+ * benchmark that wants per-kernel times AND an undisturbed frame rate samples them.  Default 1. */
+void kfh_set_profiling_stride(kfh_context *ctx, uint32_t every_n_frames);
 int kfh_read_profile(kfh_context *ctx, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]);
 
 /* Copy an internal device buffer to the host for parity checks.  name is one of

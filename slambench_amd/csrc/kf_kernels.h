@@ -56,8 +56,33 @@ struct ControlArgs {
     unsigned log_capacity;
 };
 
+// Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_kernels.hip, "side jobs"):
+// a range of 32x8 bilateral tiles or of 32x32 pyramid tiles.  All buffers belong to the other half of the double buffer.
+struct SideWork {
+    enum Kind { NONE = 0, BILATERAL = 1, PYRAMID = 2 };
+    int kind;
+    unsigned first, count;            // tile range
+    unsigned W, H;
+    // BILATERAL (mm2meters + bilateral filter, cpp:562-589 + 159-198)
+    float *floatDepth, *filtered;
+    const uint16_t *in;
+    unsigned inW;
+    int ratio;
+    Gauss5 gauss;
+    float e_d;                        // e_delta for BILATERAL, e_delta * 3 for PYRAMID
+    // PYRAMID (cpp:931-945)
+    int n_levels;
+    float *scaled[4];
+    float4 *vertex[4], *normal[4];
+    const float4 *stale_normal[4];
+    M4 invK[4];
+};
+
 namespace launch {
 unsigned track_blocks(unsigned w, unsigned h);
+unsigned bilateral_tiles(unsigned W, unsigned H);
+unsigned pyramid_tiles(unsigned W, unsigned H);
+bool pyramid_fusable(int n_levels, unsigned W, unsigned H);
 unsigned track_blocks_max();
 unsigned icp_blocks(unsigned w, unsigned h);
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
@@ -71,8 +96,8 @@ void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H,
 void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s);
 // whole input pyramid (half-sampling + vertex/normal maps of every level) in one launch; false if the shape is not
 // covered (more than 4 levels, sizes not divisible by 2^(L-1)) and the per-level kernels must be used
-bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const M4 *invK, unsigned W,
-             unsigned H, float e_d, hipStream_t s);
+bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const float4 *const *stale_normal,
+             const M4 *invK, unsigned W, unsigned H, float e_d, hipStream_t s);
 // fused ICP pass: per-pixel association + block partial sums.  pose/params/skip are device pointers.
 void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, const float4 *inVertex,
                   const float4 *inNormal, unsigned inW, unsigned inH, const float4 *refVertex, const float4 *refNormal,
@@ -87,7 +112,7 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, hipStream_t s);
+              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s);
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

@@ -97,30 +97,32 @@ __device__ __forceinline__ float expf_glibc(float x, const double *tab /* LDS co
 
 constexpr int PBX = 32, PBY = 8, PR = 2;
 
+// One 32x8 output tile.  `tid` is the thread's index inside its 256-thread tile team, `active` is false for a team
+// that only keeps the barrier company (side-job rounds of the fused ICP launch, see k_icp_iter_bilateral).
 template <bool FROM_MM>
-__global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floatDepth, float *__restrict__ out,
-                                                        const void *__restrict__ inv, unsigned W, unsigned H,
-                                                        unsigned inW, int ratio, Gauss5 g, float e_d_squared_2) {
-    __shared__ float tile[PBY + 2 * PR][PBX + 2 * PR + 1];
-    __shared__ double exp_tab[32];
-    const int x0 = blockIdx.x * PBX, y0 = blockIdx.y * PBY;
-    const int tid = threadIdx.y * PBX + threadIdx.x;
-    if (tid < 32) exp_tab[tid] = __builtin_bit_cast(double, kExp2fTable[tid]);
+__device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1], const double *exp_tab, int bx, int by, int tid,
+                                                bool active, float *__restrict__ floatDepth, float *__restrict__ out,
+                                                const void *__restrict__ inv, unsigned W, unsigned H, unsigned inW, int ratio,
+                                                const Gauss5 &g, float e_d_squared_2) {
+    const int x0 = bx * PBX, y0 = by * PBY;
     constexpr int TW = PBX + 2 * PR, TH = PBY + 2 * PR;
-    for (int idx = tid; idx < TW * TH; idx += PBX * PBY) {
-        const int ty = idx / TW, tx = idx - ty * TW;
-        const int gx = imax(0, imin(x0 + tx - PR, (int)W - 1));
-        const int gy = imax(0, imin(y0 + ty - PR, (int)H - 1));
-        float v;
-        if (FROM_MM) v = static_cast<const uint16_t *>(inv)[gx * ratio + inW * gy * ratio] / 1000.0f;
-        else v = static_cast<const float *>(inv)[gx + gy * W];
-        tile[ty][tx] = v;
+    if (active) {
+        for (int idx = tid; idx < TW * TH; idx += PBX * PBY) {
+            const int ty = idx / TW, tx = idx - ty * TW;
+            const int gx = imax(0, imin(x0 + tx - PR, (int)W - 1));
+            const int gy = imax(0, imin(y0 + ty - PR, (int)H - 1));
+            float v;
+            if (FROM_MM) v = static_cast<const uint16_t *>(inv)[gx * ratio + inW * gy * ratio] / 1000.0f;
+            else v = static_cast<const float *>(inv)[gx + gy * W];
+            tile[ty][tx] = v;
+        }
     }
     __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= (int)W || y >= (int)H) return;
+    const int lx = tid & (PBX - 1), ly = tid / PBX;
+    const int x = x0 + lx, y = y0 + ly;
+    if (!active || x >= (int)W || y >= (int)H) return;
     const unsigned pos = x + y * W;
-    const float center = tile[threadIdx.y + PR][threadIdx.x + PR];
+    const float center = tile[ly + PR][lx + PR];
     if (FROM_MM && floatDepth) floatDepth[pos] = center;
     if (center == 0) { out[pos] = 0; return; }
     float sum = 0.0f, t = 0.0f;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floa
     for (int i = -PR; i <= PR; ++i) {
 #pragma unroll
         for (int j = -PR; j <= PR; ++j) {
-            const float cur = tile[threadIdx.y + PR + j][threadIdx.x + PR + i];
+            const float cur = tile[ly + PR + j][lx + PR + i];
             if (cur > 0) {
                 const float mod = sq(cur - center);
                 const float factor = g.g[i + PR] * g.g[j + PR] * expf_glibc(-mod / e_d_squared_2, exp_tab);
@@ -138,6 +140,17 @@ __global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floa
         }
     }
     out[pos] = t / sum;
+}
+
+template <bool FROM_MM>
+__global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floatDepth, float *__restrict__ out,
+                                                        const void *__restrict__ inv, unsigned W, unsigned H,
+                                                        unsigned inW, int ratio, Gauss5 g, float e_d_squared_2) {
+    __shared__ float tile[PBY + 2 * PR][PBX + 2 * PR + 1];
+    __shared__ double exp_tab[32];
+    const int tid = threadIdx.y * PBX + threadIdx.x;
+    if (tid < 32) exp_tab[tid] = __builtin_bit_cast(double, kExp2fTable[tid]);
+    bilateral_block<FROM_MM>(tile, exp_tab, blockIdx.x, blockIdx.y, tid, true, floatDepth, out, inv, W, H, inW, ratio, g, e_d_squared_2);
 }
 
 __global__ __launch_bounds__(256) void k_mm2meters(float *__restrict__ out, unsigned W, unsigned H,
@@ -182,9 +195,15 @@ __global__ __launch_bounds__(256) void k_depth2vertex(float4 *__restrict__ verte
 }
 
 // Invalid pixels write only .x: .y/.z keep whatever the previous frame left there.
-__device__ __forceinline__ void store_normal(float4 *out, f3 left, f3 right, f3 up, f3 down) {
+// `stale`: where the previous frame's normal of this pixel lives when the maps are double-buffered (nullptr = in `out`).
+__device__ __forceinline__ void store_normal(float4 *out, f3 left, f3 right, f3 up, f3 down, const float4 *stale = nullptr) {
     if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) {
-        reinterpret_cast<float *>(out)[0] = kInvalid;
+        if (stale) {
+            const float4 o = *stale;
+            *out = make_float4(kInvalid, o.y, o.z, o.w);
+        } else {
+            reinterpret_cast<float *>(out)[0] = kInvalid;
+        }
         return;
     }
     const f3 dxv = sub3(right, left), dyv = sub3(down, up);
@@ -247,10 +266,12 @@ struct PyramidArgs {
     float *scaled[PYR_MAX_LEVELS];      // scaled[0] is the input (bilateral-filtered depth), the others are outputs
     float4 *vertex[PYR_MAX_LEVELS];
     float4 *normal[PYR_MAX_LEVELS];
+    const float4 *stale_normal[PYR_MAX_LEVELS];   // previous frame's normal maps when double-buffered, else nullptr
     M4 invK[PYR_MAX_LEVELS];
     unsigned W, H;
     float e_d;
 };
+constexpr int PYR_THREADS = 256;
 
 // halo of level l (in level-l pixels): 1 on the coarsest level, doubling towards level 0
 constexpr int pyr_halo(int nlev, int l) { int h = 1; for (int i = nlev - 1; i > l; --i) h *= 2; return h; }
@@ -268,18 +289,17 @@ struct PyrGeom {
 };
 
 template <int NLEV, int L>
-__device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, int bx, int by) {
+__device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
     using G = PyrGeom<NLEV, L>;
     const unsigned Wl = a.W >> L, Hl = a.H >> L;
     const int X0 = (bx * PYR_T) >> L, Y0 = (by * PYR_T) >> L;       // this block's tile origin at level L
     float *d = lds + G::offset;
-    const int tid = threadIdx.x;
     if constexpr (L > 0) {
         // depth of level L over the tile plus its halo, from level L-1 in LDS (robust 2x2 mean, cpp:598-623)
         using P = PyrGeom<NLEV, L - 1>;
         const float *dp = lds + P::offset;
         const int PX0 = ((bx * PYR_T) >> (L - 1)) - P::halo, PY0 = ((by * PYR_T) >> (L - 1)) - P::halo;
-        for (int idx = tid; idx < G::count; idx += blockDim.x) {
+        for (int idx = tid; idx < G::count; idx += PYR_THREADS) {
             const int ly = idx / G::stride, lx = idx - ly * G::stride;
             const int gx = X0 - G::halo + lx, gy = Y0 - G::halo + ly;
             if (gx < 0 || gy < 0 || gx >= (int)Wl || gy >= (int)Hl) continue;
@@ -301,7 +321,7 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
     }
     // vertex and normal maps of the tile (cpp:206-215, 225-247)
     const M4 invK = a.invK[L];
-    for (int idx = tid; idx < G::tile * G::tile; idx += blockDim.x) {
+    for (int idx = tid; idx < G::tile * G::tile; idx += PYR_THREADS) {
         const int ty = idx / G::tile, tx = idx - ty * G::tile;
         const int x = X0 + tx, y = Y0 + ty;
         if (x >= (int)Wl || y >= (int)Hl) continue;
@@ -313,29 +333,38 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
         const f3 u = back_project(d[(yu - oy) * G::stride + (x - ox)], x, yu, invK);
         const f3 dn = back_project(d[(yd - oy) * G::stride + (x - ox)], x, yd, invK);
         a.vertex[L][x + (size_t)y * Wl] = make_float4(c.x, c.y, c.z, 0.f);
-        store_normal(a.normal[L] + x + (size_t)y * Wl, l, r, u, dn);
+        store_normal(a.normal[L] + x + (size_t)y * Wl, l, r, u, dn, a.stale_normal[L] ? a.stale_normal[L] + x + (size_t)y * Wl : nullptr);
     }
 }
 
+// One 32x32 level-0 tile by a team of PYR_THREADS threads.  `tid` >= PYR_THREADS * 65536 marks an idle team: its loops
+// are empty and it only takes part in the barriers.
 template <int NLEV>
-__global__ __launch_bounds__(256) void k_pyramid(PyramidArgs a) {
+__device__ __forceinline__ void pyramid_block(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
     using G0 = PyrGeom<NLEV, 0>;
-    using GL = PyrGeom<NLEV, NLEV - 1>;
-    __shared__ float lds[GL::offset + GL::count];
-    const int bx = blockIdx.x, by = blockIdx.y;
     // level-0 tile with halo; taps outside the image take the nearest pixel (only the 1-pixel ring is ever read there,
     // by the clamped neighbour accesses of the normals)
     const int X0 = bx * PYR_T - G0::halo, Y0 = by * PYR_T - G0::halo;
-    for (int idx = threadIdx.x; idx < G0::count; idx += blockDim.x) {
+    for (int idx = tid; idx < G0::count; idx += PYR_THREADS) {
         const int ly = idx / G0::stride, lx = idx - ly * G0::stride;
         const int gx = imax(0, imin(X0 + lx, (int)a.W - 1)), gy = imax(0, imin(Y0 + ly, (int)a.H - 1));
         lds[idx] = a.scaled[0][gx + (size_t)gy * a.W];
     }
     __syncthreads();
-    pyramid_level<NLEV, 0>(a, lds, bx, by);
-    if constexpr (NLEV > 1) pyramid_level<NLEV, 1>(a, lds, bx, by);
-    if constexpr (NLEV > 2) pyramid_level<NLEV, 2>(a, lds, bx, by);
-    if constexpr (NLEV > 3) pyramid_level<NLEV, 3>(a, lds, bx, by);
+    pyramid_level<NLEV, 0>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 1) pyramid_level<NLEV, 1>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 2) pyramid_level<NLEV, 2>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 3) pyramid_level<NLEV, 3>(a, lds, bx, by, tid);
+}
+constexpr int PYR_IDLE = 1 << 30;
+
+template <int NLEV>
+constexpr int pyr_lds_floats() { return PyrGeom<NLEV, NLEV - 1>::offset + PyrGeom<NLEV, NLEV - 1>::count; }
+
+template <int NLEV>
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid(PyramidArgs a) {
+    __shared__ float lds[pyr_lds_floats<NLEV>()];
+    pyramid_block<NLEV>(a, lds, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 // =====================================================================================
@@ -713,19 +742,30 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     __syncthreads();
 }
 
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(
-    DevState *__restrict__ st, IcpState *__restrict__ iters, const float *__restrict__ partials_prev,
-    float *__restrict__ partials_out, int *__restrict__ result_map, int it, int level, int prev_level,
-    unsigned prev_nblocks, const float4 *__restrict__ inV, const float4 *__restrict__ inN, unsigned inW, unsigned inH,
-    const float4 *__restrict__ refV, const float4 *__restrict__ refN, unsigned refW, unsigned refH, float icp_threshold,
-    float dist_threshold, float normal_threshold) {
-    __shared__ IcpShared sh;
+struct IcpIterArgs {
+    DevState *st;
+    IcpState *iters;
+    const float *partials_prev;
+    float *partials_out;
+    int *result_map;
+    int it, level, prev_level;
+    unsigned prev_nblocks, nblocks;       // nblocks: ICP blocks of this launch (the grid may hold side-job blocks after them)
+    const float4 *inV, *inN;
+    unsigned inW, inH;
+    const float4 *refV, *refN;
+    unsigned refW, refH;
+    float icp_threshold, dist_threshold, normal_threshold;
+};
+
+__device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs &a) {
+    DevState *__restrict__ st = a.st;
+    IcpState *__restrict__ iters = a.iters;
     const bool writer = blockIdx.x == 0;
-    icp_advance(sh, st, iters, partials_prev, it, prev_level, prev_nblocks, icp_threshold, writer);
+    icp_advance(sh, st, iters, a.partials_prev, a.it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer);
     if (threadIdx.x == 0) {
-        sh.executed = sh.done[level] ? 0 : 1;
+        sh.executed = sh.done[a.level] ? 0 : 1;
         if (writer) {
-            IcpState &o = iters[it];
+            IcpState &o = iters[a.it];
             o.pose = sh.pose;
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
             o.executed = sh.executed;
@@ -739,15 +779,86 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    const unsigned n = inW * inH;
-    for (unsigned p = blockIdx.x * ICP_THREADS + threadIdx.x; p < n; p += gridDim.x * ICP_THREADS) {
-        const unsigned py = p / inW, px = p - py * inW;
-        const PixelTrack r = track_pixel(px, py, inV, inN, inW, refV, refN, refW, refH, T, view, have_reference,
-                                         dist_threshold, normal_threshold);
-        result_map[px + py * refW] = r.result;   // full-resolution row stride on every level (cpp:512)
+    const unsigned n = a.inW * a.inH;
+    const float4 *__restrict__ inV = a.inV, *__restrict__ inN = a.inN, *__restrict__ refV = a.refV, *__restrict__ refN = a.refN;
+    int *__restrict__ result_map = a.result_map;
+    for (unsigned p = blockIdx.x * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
+        const unsigned py = p / a.inW, px = p - py * a.inW;
+        const PixelTrack r = track_pixel(px, py, inV, inN, a.inW, refV, refN, a.refW, a.refH, T, view, have_reference,
+                                         a.dist_threshold, a.normal_threshold);
+        result_map[px + py * a.refW] = r.result;   // full-resolution row stride on every level (cpp:512)
         accumulate(acc, r.result, r.error, r.J);
     }
-    block_reduce_store<ICP_THREADS>(acc, partials_out + (size_t)blockIdx.x * 32);
+    block_reduce_store<ICP_THREADS>(acc, a.partials_out + (size_t)blockIdx.x * 32);
+}
+
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(IcpIterArgs a) {
+    __shared__ IcpShared sh;
+    icp_iter_block(sh, a);
+}
+
+// ---- side jobs ----------------------------------------------------------------------------------------------------
+// The ICP launches of the coarse pyramid levels occupy 19 (160x120) or 75 (320x240) of the 256 CUs and are bound by
+// dependent latencies.  The queued-frame path (kfh_compute_frame) uses the idle CUs for the input-only work of the
+// NEXT frame - mm2meters + bilateral filter, then the input pyramid - which depends on nothing the current frame
+// computes: blocks past `a.nblocks` run tiles of that work, in teams of 256 threads (one block = 4 teams), each team
+// executing the very routine the stand-alone kernel runs.  The maps are double-buffered by the caller, so the ICP
+// blocks of this launch and the side blocks never touch the same buffer.
+struct SideBilateral {
+    float *floatDepth, *out;
+    const void *in;
+    unsigned W, H, inW;
+    int ratio;
+    Gauss5 g;
+    float e_d_squared_2;
+    unsigned first, count;    // range of 32x8 tiles (row-major over the tile grid) this launch covers
+};
+
+struct SidePyramid {
+    PyramidArgs a;
+    unsigned first, count;    // range of 32x32 tiles
+};
+
+constexpr int SIDE_TEAMS = ICP_THREADS / 256;
+
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bilateral(IcpIterArgs a, SideBilateral sb) {
+    __shared__ IcpShared sh;
+    __shared__ float tiles[SIDE_TEAMS][PBY + 2 * PR][PBX + 2 * PR + 1];
+    __shared__ double exp_tab[32];
+    if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
+    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks;
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = __builtin_bit_cast(double, kExp2fTable[threadIdx.x]);
+    const unsigned tiles_x = (sb.W + PBX - 1) / PBX;
+    // tile i of the range goes to block i % nside, team (i / nside) % SIDE_TEAMS: the range is spread over all side blocks
+    // (one per idle CU) before any block gets a second tile, and every block runs the same number of rounds
+    const unsigned rounds = (sb.count + nside * SIDE_TEAMS - 1) / (nside * SIDE_TEAMS);
+    for (unsigned r = 0; r < rounds; ++r) {
+        const unsigned i = (r * SIDE_TEAMS + team) * nside + side;
+        const bool active = i < sb.count;
+        const unsigned t = sb.first + i;
+        bilateral_block<true>(tiles[team], exp_tab, (int)(t % tiles_x), (int)(t / tiles_x), tid, active, sb.floatDepth, sb.out, sb.in,
+                              sb.W, sb.H, sb.inW, sb.ratio, sb.g, sb.e_d_squared_2);
+        __syncthreads();   // the tiles are reused by the next round
+    }
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
+    __shared__ IcpShared sh;
+    __shared__ float lds[SIDE_TEAMS][pyr_lds_floats<NLEV>()];
+    if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
+    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks;
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
+    const unsigned rounds = (sp.count + nside * SIDE_TEAMS - 1) / (nside * SIDE_TEAMS);
+    for (unsigned r = 0; r < rounds; ++r) {
+        const unsigned i = (r * SIDE_TEAMS + team) * nside + side;
+        const bool active = i < sp.count;
+        const unsigned t = sp.first + i;
+        pyramid_block<NLEV>(sp.a, lds[team], (int)(t % tiles_x), (int)(t / tiles_x), active ? tid : PYR_IDLE);
+        __syncthreads();
+    }
 }
 
 // Closes the loop: the update of the last iteration, then the scalar glue that follows tracking (checkPose, integrate
@@ -1463,15 +1574,15 @@ void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned 
     k_vertex_normal<<<grid, block, 0, s>>>(vertex, normal, depth, W, H, invK);
 }
 
-bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const M4 *invK, unsigned W,
-             unsigned H, float e_d, hipStream_t s) {
-    if (n_levels < 1 || n_levels > PYR_MAX_LEVELS) return false;
-    if (W % (1u << (n_levels - 1)) != 0 || H % (1u << (n_levels - 1)) != 0) return false;   // keep odd sizes on the simple path
+bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const float4 *const *stale_normal,
+             const M4 *invK, unsigned W, unsigned H, float e_d, hipStream_t s) {
+    if (!pyramid_fusable(n_levels, W, H)) return false;   // keep odd sizes on the simple path
     PyramidArgs a;
     for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
         a.scaled[l] = l < n_levels ? scaled[l] : nullptr;
         a.vertex[l] = l < n_levels ? vertex[l] : nullptr;
         a.normal[l] = l < n_levels ? normal[l] : nullptr;
+        a.stale_normal[l] = (l < n_levels && stale_normal) ? stale_normal[l] : nullptr;
         a.invK[l] = l < n_levels ? invK[l] : identity4();
     }
     a.W = W; a.H = H; a.e_d = e_d;
@@ -1507,13 +1618,67 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
     k_control<<<1, 64, 0, s>>>(st, log, ops, a);
 }
 
+static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map,
+                                 int it, int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV,
+                                 const float4 *inN, unsigned inW, unsigned inH, const float4 *refV, const float4 *refN,
+                                 unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold) {
+    IcpIterArgs a;
+    a.st = st; a.iters = iters; a.partials_prev = partials_prev; a.partials_out = partials_out; a.result_map = result_map;
+    a.it = it; a.level = level; a.prev_level = prev_level; a.prev_nblocks = prev_nblocks; a.nblocks = nblocks;
+    a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
+    a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
+    return a;
+}
+
+// side blocks of a launch: one per tile team group, at most what the ICP blocks leave free on the chip
+static unsigned side_blocks(unsigned tiles, unsigned icp_nb) {
+    const unsigned room = icp_nb < 224 ? 256 - icp_nb : 32;     // one block per CU the ICP blocks leave idle
+    return tiles < room ? (tiles ? tiles : 1) : room;
+}
+
+unsigned bilateral_tiles(unsigned W, unsigned H) { return ((W + PBX - 1) / PBX) * ((H + PBY - 1) / PBY); }
+unsigned pyramid_tiles(unsigned W, unsigned H) { return ((W + PYR_T - 1) / PYR_T) * ((H + PYR_T - 1) / PYR_T); }
+bool pyramid_fusable(int n_levels, unsigned W, unsigned H) {
+    return n_levels >= 1 && n_levels <= PYR_MAX_LEVELS && W % (1u << (n_levels - 1)) == 0 && H % (1u << (n_levels - 1)) == 0;
+}
+
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, hipStream_t s) {
-    k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(st, iters, partials_prev, partials_out, result_map, it, level, prev_level,
-                                              prev_nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold,
-                                              dist_threshold, normal_threshold);
+              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s) {
+    const IcpIterArgs a = make_icp_args(st, iters, partials_prev, partials_out, result_map, it, level, prev_level, prev_nblocks,
+                                        nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
+                                        normal_threshold);
+    if (side && side->kind == SideWork::BILATERAL && side->count) {
+        SideBilateral sb;
+        sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
+        sb.inW = side->inW; sb.ratio = side->ratio; sb.g = side->gauss; sb.e_d_squared_2 = side->e_d * side->e_d * 2;
+        sb.first = side->first; sb.count = side->count;
+        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks), ICP_THREADS, 0, s>>>(a, sb);
+        return;
+    }
+    if (side && side->kind == SideWork::PYRAMID && side->count) {
+        SidePyramid sp;
+        for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
+            const bool on = l < side->n_levels;
+            sp.a.scaled[l] = on ? side->scaled[l] : nullptr;
+            sp.a.vertex[l] = on ? side->vertex[l] : nullptr;
+            sp.a.normal[l] = on ? side->normal[l] : nullptr;
+            sp.a.stale_normal[l] = on ? side->stale_normal[l] : nullptr;
+            sp.a.invK[l] = on ? side->invK[l] : identity4();
+        }
+        sp.a.W = side->W; sp.a.H = side->H; sp.a.e_d = side->e_d;
+        sp.first = side->first; sp.count = side->count;
+        const unsigned grid = nblocks + side_blocks(side->count, nblocks);
+        switch (side->n_levels) {
+        case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 3: k_icp_iter_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        default: k_icp_iter_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        }
+        return;
+    }
+    k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a);
 }
 
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,

@@ -58,6 +58,19 @@ struct kfh_context {
     float *d_floatDepth = nullptr;
     std::vector<float *> d_scaled;
     std::vector<float4 *> d_inV, d_inN;
+    // second half of the double buffer of the input maps (queued-frame path: the next frame's preprocessing runs while
+    // the current frame still reads its own maps).  The d_* members above always name the newest frame's maps.
+    float *alt_floatDepth = nullptr;
+    std::vector<float *> alt_scaled;
+    std::vector<float4 *> alt_inV, alt_inN;
+    bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
+    struct PendingFrame {
+        bool valid = false;
+        bool pyramid_ready = false;
+        float k[4] = {0, 0, 0, 0};
+        float icp_threshold = 0, mu = 0;
+        unsigned frame = 0, tracking_rate = 1, integration_rate = 1;
+    } pend;
     float4 *d_vertex = nullptr, *d_normal = nullptr;
     int *d_result = nullptr;
     float *d_partials = nullptr;      // two buffers of track_blocks_max() x 32, alternating by ICP iteration
@@ -79,6 +92,8 @@ struct kfh_context {
     std::vector<PendingCopy> pending;
     // optional HIP-event timing of pipeline phases (kfh_set_profiling)
     unsigned prof_mask = 0;
+    unsigned prof_stride = 1, prof_tick = 0;   // queued frames: events around every prof_stride-th frame only
+    bool prof_now = true;
     std::vector<hipEvent_t> prof_events[KFH_PROF_COUNT];   // start/stop pairs, in issue order
     size_t prof_used[KFH_PROF_COUNT] = {};
     double prof_ms[KFH_PROF_COUNT] = {};
@@ -119,12 +134,12 @@ static void prof_collect(kfh_context *c) {
     }
 }
 static inline void prof_begin(kfh_context *c, int phase) {
-    if (!(c->prof_mask & (1u << phase))) return;
+    if (!(c->prof_mask & (1u << phase)) || !c->prof_now) return;
     if (c->prof_used[phase] >= 16384) prof_collect(c);
     HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
 }
 static inline void prof_end(kfh_context *c, int phase) {
-    if (!(c->prof_mask & (1u << phase))) return;
+    if (!(c->prof_mask & (1u << phase)) || !c->prof_now) return;
     HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
 }
 
@@ -142,7 +157,9 @@ static void fill_control(const kfh_context *c, ControlArgs &a, const float k[4],
     a.log_capacity = c->log_capacity;
 }
 
+static void finish_pending_frame(kfh_context *c, const struct NextFrameWork *next);
 static void refresh_mirror(kfh_context *c) {
+    if (c->pend.valid) finish_pending_frame(c, nullptr);
     if (!c->mirror_stale) return;
     HIP_TRY(hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -169,26 +186,35 @@ static int enqueue_preprocess(kfh_context *c, const uint16_t *d_in, unsigned inW
     return 1;
 }
 
-// Queues the pyramid and the whole ICP loop.  `end_ops` are the control operations that follow tracking; they ride on
-// the launch that applies the last ICP update (or on a plain control launch when this frame is not tracked).
-static void enqueue_tracking(kfh_context *c, const float k[4], float icp_threshold, unsigned tracking_rate, unsigned frame,
-                             int end_ops, unsigned integration_rate) {
-    ControlArgs a;
-    fill_control(c, a, k, frame, tracking_rate, integration_rate);
-    if (frame % a.tracking_rate != 0) {   // cpp:927-928: nothing runs, not even the pyramid
-        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN | end_ops, a, c->stream);
-        return;
+static std::vector<int> parse_int_list(const char *e) {
+    std::vector<int> v;
+    if (!e) return v;
+    for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long x = strtol(p, &end, 10);
+        if (end == p) break;
+        v.push_back((int)x);
+        p = (*end == ',') ? end + 1 : end;
     }
-    const int L = (int)c->iterations.size();
-    prof_begin(c, KFH_PROF_PYRAMID);
-    M4 invKs[KFH_MAX_LEVELS];
+    return v;
+}
+
+static void camera_pyramid(const float k[4], int L, M4 *invKs) {
     for (int i = 0; i < L; ++i) {   // cpp:940
         const float sc = float(1 << i);
         invKs[i] = inverse_camera_matrix(k[0] / sc, k[1] / sc, k[2] / sc, k[3] / sc);
     }
+}
+
+// Input pyramid of the newest frame (cpp:931-945) as launches of its own.
+static void enqueue_pyramid(kfh_context *c, const float k[4]) {
+    const int L = (int)c->iterations.size();
+    prof_begin(c, KFH_PROF_PYRAMID);
+    M4 invKs[KFH_MAX_LEVELS];
+    camera_pyramid(k, L, invKs);
     static const bool fused_env = [] { const char *e = getenv("KFH_NO_FUSED_PYRAMID"); return !(e && e[0] == '1'); }();
-    const bool fused = fused_env && launch::pyramid(L, c->d_scaled.data(), c->d_inV.data(), c->d_inN.data(), invKs, c->W, c->H,
-                                                    e_delta * 3, c->stream);
+    const bool fused = fused_env && launch::pyramid(L, c->d_scaled.data(), c->d_inV.data(), c->d_inN.data(), nullptr, invKs, c->W,
+                                                    c->H, e_delta * 3, c->stream);
     if (!fused) {
         for (int i = 1; i < L; ++i)   // cpp:931-935
             launch::half_sample(c->d_scaled[i], c->d_scaled[i - 1], level_dim(c->W, i - 1), level_dim(c->H, i - 1),
@@ -200,6 +226,84 @@ static void enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         }
     }
     prof_end(c, KFH_PROF_PYRAMID);
+}
+
+// What the next frame needs before its own tracking can start: mm2meters + bilateral filter and (if that frame is
+// tracked) the input pyramid, written to the alt_* half of the double buffer.
+struct NextFrameWork {
+    const uint16_t *d_in = nullptr;
+    unsigned inW = 0, inH = 0;
+    bool pyramid = false;
+    float k[4] = {0, 0, 0, 0};
+};
+
+static void fill_side_bilateral(const kfh_context *c, const NextFrameWork &nw, SideWork &w, unsigned first, unsigned count) {
+    std::memset(&w, 0, sizeof w);
+    w.kind = SideWork::BILATERAL;
+    w.first = first; w.count = count; w.W = c->W; w.H = c->H;
+    w.floatDepth = c->alt_floatDepth; w.filtered = c->alt_scaled[0];
+    w.in = nw.d_in; w.inW = nw.inW; w.ratio = (int)(nw.inW / c->W);
+    w.gauss = c->gauss; w.e_d = e_delta;
+}
+
+static void fill_side_pyramid(const kfh_context *c, const NextFrameWork &nw, SideWork &w, unsigned first, unsigned count) {
+    std::memset(&w, 0, sizeof w);
+    const int L = (int)c->iterations.size();
+    w.kind = SideWork::PYRAMID;
+    w.first = first; w.count = count; w.W = c->W; w.H = c->H;
+    w.e_d = e_delta * 3;
+    w.n_levels = L;
+    M4 invKs[KFH_MAX_LEVELS];
+    camera_pyramid(nw.k, L, invKs);
+    for (int l = 0; l < L; ++l) {
+        w.scaled[l] = c->alt_scaled[l]; w.vertex[l] = c->alt_inV[l]; w.normal[l] = c->alt_inN[l];
+        w.stale_normal[l] = c->d_inN[l];    // an invalid normal keeps the y/z the previous frame left
+        w.invK[l] = invKs[l];
+    }
+}
+
+// Queues the pyramid (unless `pyramid_ready`) and the whole ICP loop.  `end_ops` are the control operations that follow
+// tracking; they ride on the launch that applies the last ICP update (or on a plain control launch when this frame is
+// not tracked).  `next`, if given, is the next frame's input work: it is spread over the first ICP launches of the
+// coarse levels as side jobs; returns false if it could not be placed (the caller then runs it stand-alone).
+static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_threshold, unsigned tracking_rate, unsigned frame,
+                             int end_ops, unsigned integration_rate, bool pyramid_ready = false,
+                             const NextFrameWork *next = nullptr) {
+    ControlArgs a;
+    fill_control(c, a, k, frame, tracking_rate, integration_rate);
+    if (frame % a.tracking_rate != 0) {   // cpp:927-928: nothing runs, not even the pyramid
+        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN | end_ops, a, c->stream);
+        return false;
+    }
+    const int L = (int)c->iterations.size();
+    if (!pyramid_ready) enqueue_pyramid(c, k);
+    // side-job plan.  A side block costs what its CU's share of tiles costs (~2.3 us per 32x8 bilateral tile team round,
+    // ~8 us of latency for a pyramid tile), and the launch lasts as long as its slowest block, so: the bilateral filter
+    // is split over TWO launches (2.5 tiles per idle CU each, shorter than the ICP iteration it rides on), the pyramid
+    // takes one, and all three go on launches that are long anyway - executed iterations with a solve in front of them
+    // (iteration 0 of a frame has none and is short; late iterations of a level are usually skipped).
+    int coarse_launches = 0;
+    for (int level = L - 1; level >= 1; --level) coarse_launches += c->iterations[level] > 0 ? c->iterations[level] : 0;
+    std::vector<int> bil_its, pyr_its;
+    if (next) {
+        static const std::vector<int> bil_env = parse_int_list(getenv("KFH_SIDE_BIL_ITS")), pyr_env = parse_int_list(getenv("KFH_SIDE_PYR_ITS"));
+        const int first_l1 = c->iterations[L - 1] > 0 ? c->iterations[L - 1] : 0;    // first launch of the second-coarsest level
+        if (!bil_env.empty() && (!next->pyramid || !pyr_env.empty())) { bil_its = bil_env; if (next->pyramid) pyr_its = pyr_env; }
+        else if (next->pyramid) {
+            if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
+            else if (coarse_launches >= 3) { bil_its = {0, 1}; pyr_its = {2}; }
+            else if (coarse_launches == 2) { bil_its = {0}; pyr_its = {1}; }
+        } else if (coarse_launches >= 3) bil_its = {1, 2};
+        else if (coarse_launches >= 1) bil_its = {0};
+        // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
+        bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
+        int last = -1;
+        for (int v : bil_its) { ok = ok && v > last && v < coarse_launches; last = v; }
+        for (int v : pyr_its) { ok = ok && v > last && v < coarse_launches; last = v; }
+        if (!ok) { bil_its.clear(); pyr_its.clear(); }
+    }
+    const bool placed = next && !bil_its.empty();
+    const unsigned bil_tiles = launch::bilateral_tiles(c->W, c->H), pyr_tiles = launch::pyramid_tiles(c->W, c->H);
     prof_begin(c, KFH_PROF_ICP);
     launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
     float *part[2] = {c->d_partials, c->d_partials + (size_t)launch::track_blocks_max() * 32};
@@ -209,15 +313,30 @@ static void enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
         const unsigned nb = launch::icp_blocks(w, h);
         for (int i = 0; i < c->iterations[level]; ++i) {
+            SideWork side;
+            const SideWork *sp = nullptr;
+            for (size_t j = 0; placed && j < bil_its.size(); ++j)
+                if (bil_its[j] == it) {
+                    const unsigned lo = (unsigned)((unsigned long long)bil_tiles * j / bil_its.size()), hi = (unsigned)((unsigned long long)bil_tiles * (j + 1) / bil_its.size());
+                    fill_side_bilateral(c, *next, side, lo, hi - lo);
+                    sp = &side;
+                }
+            for (size_t j = 0; placed && j < pyr_its.size(); ++j)
+                if (pyr_its[j] == it) {
+                    const unsigned lo = (unsigned)((unsigned long long)pyr_tiles * j / pyr_its.size()), hi = (unsigned)((unsigned long long)pyr_tiles * (j + 1) / pyr_its.size());
+                    fill_side_pyramid(c, *next, side, lo, hi - lo);
+                    sp = &side;
+                }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
-                             dist_threshold, normal_threshold, c->stream);
+                             dist_threshold, normal_threshold, sp, c->stream);
             prev_level = level; prev_nb = nb; ++it;
         }
     }
     if (it > 0) launch::icp_final(c->d_state, c->d_log, c->d_icp, part[(it + 1) & 1], it, prev_level, prev_nb, icp_threshold, end_ops, a, c->stream);
     else launch::control(c->d_state, c->d_log, end_ops, a, c->stream);
     prof_end(c, KFH_PROF_ICP);
+    return placed;
 }
 
 static void enqueue_integrate(kfh_context *c, float mu) {
@@ -232,6 +351,48 @@ static void enqueue_raycast(kfh_context *c, float mu) {
     launch::raycast(c->d_vertex, c->d_normal, c->W, c->H, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
                     &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->stream);
     prof_end(c, KFH_PROF_RAYCAST);
+}
+
+// ------------------------------------------------------------------ queued frames (kfh_compute_frame)
+// A queued frame is split in two: its input-only part (mm2meters, bilateral filter, input pyramid) and the part that
+// depends on the previous frame's result (ICP, integration, raycast).  The second part of frame n is issued by the call
+// that queues frame n+1 - so that the first part of n+1 can ride on the coarse ICP launches of n, which leave most of
+// the chip idle - or by any call that needs the result (kfh_synchronise, getters, phase calls, renders): those finish
+// the deferred frame first, so nothing the host can observe depends on this.
+static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
+    const kfh_context::PendingFrame p = c->pend;
+    bool next_done = false;
+    if (p.valid) {
+        c->prof_now = c->prof_mask && (c->prof_tick++ % c->prof_stride) == 0;
+        next_done = enqueue_tracking(c, p.k, p.icp_threshold, p.tracking_rate, p.frame,
+                                     OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END, p.integration_rate, p.pyramid_ready, next);
+        // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the integrate
+        // gate (tracking verdict) is the device flag the kernel reads
+        if ((p.frame % p.integration_rate) == 0 || p.frame <= 3) enqueue_integrate(c, p.mu);
+        if (p.frame > 2) enqueue_raycast(c, p.mu);
+        c->pend.valid = false;
+        c->mirror_stale = true;
+    }
+    if (!next) return;
+    if (next_done) {
+        // the side jobs wrote the other half of the double buffer: it now holds the newest frame
+        std::swap(c->d_floatDepth, c->alt_floatDepth);
+        std::swap(c->d_scaled[0], c->alt_scaled[0]);
+        if (next->pyramid) {
+            for (size_t l = 1; l < c->d_scaled.size(); ++l) std::swap(c->d_scaled[l], c->alt_scaled[l]);
+            std::swap(c->d_inV, c->alt_inV);
+            std::swap(c->d_inN, c->alt_inN);
+        }
+    } else {
+        // nothing to ride on (first frame, untracked frame, single-level pyramid): plain launches, in place
+        enqueue_preprocess(c, next->d_in, next->inW, next->inH);
+        if (next->pyramid) enqueue_pyramid(c, next->k);
+    }
+}
+
+static inline void flush_frame(kfh_context *c) {
+    if (c && c->pend.valid) finish_pending_frame(c, nullptr);
+    if (c) c->prof_now = true;   // phase calls and renders are always timed when their phase is enabled
 }
 
 static const uint16_t *stage_input(kfh_context *c, const uint16_t *host, unsigned inW, unsigned inH) {
@@ -297,6 +458,27 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
             HIP_TRY(hipMemsetAsync(c->d_inV[i], 0, n * sizeof(float4), c->stream));
             HIP_TRY(hipMemsetAsync(c->d_inN[i], 0, n * sizeof(float4), c->stream));
         }
+    }
+    // queued-frame pipelining (kfh_compute_frame): needs the fused pyramid shape; KFH_PIPELINE=0 or KERNEL_TIMINGS disable it
+    {
+        const char *e = getenv("KFH_PIPELINE");
+        c->pipelined = !(e && e[0] == '0') && !getenv("KERNEL_TIMINGS") && launch::pyramid_fusable(n_levels, width, height);
+    }
+    if (c->pipelined) {
+        ok &= HIP_TRY(hipMalloc(&c->alt_floatDepth, P * sizeof(float)));
+        c->alt_scaled.resize(n_levels); c->alt_inV.resize(n_levels); c->alt_inN.resize(n_levels);
+        for (int i = 0; i < n_levels; ++i) {
+            const size_t n = P / (size_t)(int)pow(2, i);
+            ok &= HIP_TRY(hipMalloc(&c->alt_scaled[i], n * sizeof(float)));
+            ok &= HIP_TRY(hipMalloc(&c->alt_inV[i], n * sizeof(float4)));
+            ok &= HIP_TRY(hipMalloc(&c->alt_inN[i], n * sizeof(float4)));
+            if (ok) {
+                HIP_TRY(hipMemsetAsync(c->alt_scaled[i], 0, n * sizeof(float), c->stream));
+                HIP_TRY(hipMemsetAsync(c->alt_inV[i], 0, n * sizeof(float4), c->stream));
+                HIP_TRY(hipMemsetAsync(c->alt_inN[i], 0, n * sizeof(float4), c->stream));
+            }
+        }
+        if (ok) HIP_TRY(hipMemsetAsync(c->alt_floatDepth, 0, P * sizeof(float), c->stream));
     }
     ok &= HIP_TRY(hipMalloc(&c->d_vertex, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_normal, P * sizeof(float4)));
@@ -365,12 +547,17 @@ kfh_context *kfh_create_with_pose(uint32_t width, uint32_t height, const uint32_
 void kfh_destroy(kfh_context *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    c->pend.valid = false;   // a frame still deferred is dropped with the context
     if (c->stream) hipStreamSynchronize(c->stream);
     flush_pending(c);
     hipFree(c->d_input); hipFree(c->d_floatDepth);
     for (float *p : c->d_scaled) hipFree(p);
     for (float4 *p : c->d_inV) hipFree(p);
     for (float4 *p : c->d_inN) hipFree(p);
+    hipFree(c->alt_floatDepth);
+    for (float *p : c->alt_scaled) hipFree(p);
+    for (float4 *p : c->alt_inV) hipFree(p);
+    for (float4 *p : c->alt_inN) hipFree(p);
     hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip);
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
@@ -382,11 +569,13 @@ void kfh_destroy(kfh_context *c) {
 }
 
 void kfh_reset(kfh_context *c) {
+    flush_frame(c);
     launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     HIP_TRY(hipMemsetAsync(c->d_skip, 0, launch::skip_grid_bytes(c->volRes[0], c->volRes[1], c->volRes[2]), c->stream));
 }
 
 void kfh_synchronise(kfh_context *c) {
+    flush_frame(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->kernel_timings) prof_collect(c);
     flush_pending(c);
@@ -394,6 +583,7 @@ void kfh_synchronise(kfh_context *c) {
 
 int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) {
     if (!c || !host_depth_mm) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     if (in_width < c->W || in_height < c->H || in_width % c->W || in_height % c->H || in_width / c->W != in_height / c->H) {
         fprintf(stderr, "Invalid ratio.\n");
         return KFH_ERR_INVALID_RATIO;
@@ -405,6 +595,7 @@ int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in
 
 int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height) {
     if (!c || !device_depth_mm) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     const int r = enqueue_preprocess(c, device_depth_mm, in_width, in_height);
     if (r == KFH_ERR_INVALID_RATIO) fprintf(stderr, "Invalid ratio.\n");
     return r;
@@ -412,6 +603,7 @@ int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, ui
 
 int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame) {
     if (!c || !k || !tracking_rate) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END, 1);
     c->mirror_stale = true;
     refresh_mirror(c);
@@ -420,6 +612,7 @@ int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t
 
 int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate, float mu, uint32_t frame) {
     if (!c || !k || !integration_rate) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     ControlArgs a;
     fill_control(c, a, k, frame, 1, integration_rate);
     launch::control(c->d_state, c->d_log, OP_INTEG_BEGIN, a, c->stream);
@@ -431,6 +624,7 @@ int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate,
 
 int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
     if (!c || !k) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     ControlArgs a;
     fill_control(c, a, k, frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
@@ -442,16 +636,32 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
                       uint32_t in_height, const float k[4], uint32_t integration_rate, uint32_t tracking_rate,
                       float icp_threshold, float mu, uint32_t frame) {
     if (!c || !depth_mm || !k || !integration_rate || !tracking_rate) return KFH_ERR_ARGUMENT;
-    int r;
-    if (depth_is_device) r = kfh_preprocessing_device(c, depth_mm, in_width, in_height);
-    else r = kfh_preprocessing(c, depth_mm, in_width, in_height);
-    if (r < 0) return r;
-    enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END,
-                     integration_rate);
-    // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the
-    // integrate gate (tracking verdict) is the device flag the kernel reads
-    if ((frame % integration_rate) == 0 || frame <= 3) enqueue_integrate(c, mu);
-    if (frame > 2) enqueue_raycast(c, mu);
+    if (!c->pipelined) {
+        int r;
+        if (depth_is_device) r = kfh_preprocessing_device(c, depth_mm, in_width, in_height);
+        else r = kfh_preprocessing(c, depth_mm, in_width, in_height);
+        if (r < 0) return r;
+        c->pend.valid = true;
+        c->pend.pyramid_ready = false;
+    } else {
+        if (in_width < c->W || in_height < c->H || in_width % c->W || in_height % c->H || in_width / c->W != in_height / c->H) {
+            fprintf(stderr, "Invalid ratio.\n");
+            return KFH_ERR_INVALID_RATIO;
+        }
+        NextFrameWork nw;
+        nw.d_in = depth_is_device ? depth_mm : stage_input(c, depth_mm, in_width, in_height);
+        if (!nw.d_in) return KFH_ERR_HIP;
+        nw.inW = in_width; nw.inH = in_height;
+        nw.pyramid = (frame % tracking_rate) == 0;
+        for (int i = 0; i < 4; ++i) nw.k[i] = k[i];
+        finish_pending_frame(c, &nw);    // the previous queued frame's second part, with this frame's first part riding on it
+        c->pend.valid = true;
+        c->pend.pyramid_ready = nw.pyramid;
+    }
+    for (int i = 0; i < 4; ++i) c->pend.k[i] = k[i];
+    c->pend.icp_threshold = icp_threshold; c->pend.mu = mu;
+    c->pend.frame = frame; c->pend.tracking_rate = tracking_rate; c->pend.integration_rate = integration_rate;
+    if (!c->pipelined) flush_frame(c);
     c->mirror_stale = true;
     return KFH_OK;
 }
@@ -466,6 +676,7 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
 
 void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     if (!c || !out || w != c->W || h != c->H) return;
+    flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_DEPTH);
     launch::render_depth(c->d_render[0], c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
     prof_end(c, KFH_PROF_RENDER_DEPTH);
@@ -474,6 +685,7 @@ void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
 
 void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     if (!c || !out || w != c->W || h != c->H) return;
+    flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_TRACK);
     launch::render_track(c->d_render[1], c->d_result, w, h, c->stream);
     prof_end(c, KFH_PROF_RENDER_TRACK);
@@ -483,6 +695,7 @@ void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
 void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, int32_t rate, const float k[4],
                        float largestep) {
     if (!c || !out || !k || w != c->W || h != c->H || rate == 0) return;
+    flush_frame(c);
     if (frame % rate != 0) return;   // cpp:1034
     ControlArgs a;
     fill_control(c, a, k, (unsigned)frame, 1, 1);
@@ -498,6 +711,7 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
 
 int kfh_dump_volume(kfh_context *c, const char *filename) {
     if (!c) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     if (!filename) return KFH_OK;   // cpp:1010-1012
     printf("Dumping the volumetric representation on file: %s\n", filename);
     const size_t n = (size_t)c->volRes[0] * c->volRes[1] * c->volRes[2];
@@ -538,6 +752,7 @@ void kfh_get_computation_resolution(kfh_context *c, uint32_t o[2]) { o[0] = c->W
 
 int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracked, int32_t *integrated) {
     if (!c || n > c->log_capacity) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     std::vector<FrameLogEntry> host(n);
     if (n) {
         if (!HIP_TRY(hipMemcpyAsync(host.data(), c->d_log, n * sizeof(FrameLogEntry), hipMemcpyDeviceToHost, c->stream))) return KFH_ERR_HIP;
@@ -555,13 +770,21 @@ uint64_t kfh_solve_fallbacks(kfh_context *c) { c->mirror_stale = true; refresh_m
 uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
 
 void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
+    flush_frame(c);
     prof_collect(c);
     c->prof_mask = c->kernel_timings ? ((1u << KFH_PROF_COUNT) - 1u) : phase_mask;
     for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; }
 }
 
+void kfh_set_profiling_stride(kfh_context *c, uint32_t every_n_frames) {
+    if (!c) return;
+    c->prof_stride = every_n_frames ? every_n_frames : 1;
+    c->prof_tick = 0;
+}
+
 int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]) {
     if (!c) return KFH_ERR_ARGUMENT;
+    flush_frame(c);
     prof_collect(c);
     for (int p = 0; p < KFH_PROF_COUNT; ++p) { if (ms_out) ms_out[p] = c->prof_ms[p]; if (launches_out) launches_out[p] = c->prof_n[p]; }
     return KFH_OK;
@@ -595,6 +818,7 @@ static bool find_buffer(kfh_context *c, const std::string &n, void **ptr, size_t
 
 int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64_t capacity) {
     void *p; size_t b;
+    flush_frame(c);
     if (!c || !name || !find_buffer(c, name, &p, &b)) return KFH_ERR_ARGUMENT;
     if (!host_out) return (int64_t)b;
     if (capacity < b) return KFH_ERR_ARGUMENT;
@@ -605,6 +829,7 @@ int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64
 
 int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, uint64_t nbytes) {
     void *p; size_t b;
+    flush_frame(c);
     if (!c || !name || !host_in || !find_buffer(c, name, &p, &b) || nbytes != b) return KFH_ERR_ARGUMENT;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!HIP_TRY(hipMemcpy(p, host_in, b, hipMemcpyHostToDevice))) return KFH_ERR_HIP;
@@ -616,6 +841,7 @@ int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, 
 
 void *kfh_device_pointer(kfh_context *c, const char *name) {
     void *p; size_t b;
+    flush_frame(c);
     if (!c || !name || !find_buffer(c, name, &p, &b)) return nullptr;
     return p;
 }

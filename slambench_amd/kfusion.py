@@ -161,11 +161,14 @@ class Kfusion:
 
     PHASES = ("preprocess", "pyramid", "icp", "integrate", "raycast", "render_depth", "render_track", "render_volume")
 
-    def set_profiling(self, phases=()):
+    def set_profiling(self, phases=(), every=1):
+        """Time the named phases with HIP events; `every` > 1 samples every n-th queued frame (an event record stalls
+        the queue for a few microseconds, see kfusion_hip.h)."""
         mask = 0
         for p in phases:
             mask |= 1 << self.PHASES.index(p)
         self.L.kfh_set_profiling(self.h, mask)
+        self.L.kfh_set_profiling_stride(self.h, max(1, int(every)))
 
     def read_profile(self):
         """{phase: (total_ms, launches)} measured with HIP events on the backend's stream."""

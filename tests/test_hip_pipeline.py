@@ -108,6 +108,36 @@ def test_compute_frame_equals_phases(hip, kfmod):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("tracking_rate,integration_rate,pyramid,peek", [(1, 2, (10, 5, 4), False), (2, 3, (10, 5, 4), False),
+                                                                       (1, 1, (4, 3), True), (1, 2, (6,), False), (3, 1, (5, 5, 4, 3), False)])
+def test_queued_frames_ride_on_icp_launches(hip, kfmod, tracking_rate, integration_rate, pyramid, peek):
+    """kfh_compute_frame defers a frame's tracking/integration/raycast to the next call so that the next frame's
+    preprocessing can run as side jobs of the coarse ICP launches, on a double buffer.  Everything observable must be
+    what the four phase calls produce - including the input maps (all four floats per pixel: an invalid normal keeps
+    the previous frame's y/z), with untracked frames in between, and when the host peeks mid-stream."""
+    s = util.small_stream(N_FRAMES)
+    k = list(s.k)
+    res = (48, 48, 48)
+    a, b = _make(kfmod, s, res, pyramid), _make(kfmod, s, res, pyramid)
+    names = ["floatDepth", "trackResult", "vertex", "normal", "volume", "pose", "raycastPose"]
+    for l in range(len(pyramid)):
+        names += ["scaledDepth%d" % l, "inputVertex%d" % l, "inputNormal%d" % l]
+    for f in range(N_FRAMES):
+        a.preprocessing(s.depth_mm[f]); a.tracking(k, util.ICP_THRESHOLD, tracking_rate, f)
+        a.integration(k, integration_rate, util.MU, f); a.raycasting(k, util.MU, f)
+        b.compute_frame(s.depth_mm[f], (s.width, s.height), k, integration_rate, tracking_rate, util.ICP_THRESHOLD, util.MU, f)
+        if peek or f in (2, 6, N_FRAMES - 1):     # reading anything finishes the deferred frame first
+            for n in names:
+                assert np.array_equal(a.buffer(n).view(np.uint8), b.buffer(n).view(np.uint8)), (f, n)
+            assert a.get_tracked() == b.get_tracked() and a.get_integrated() == b.get_integrated()
+    pa, ta, ia = a.frame_log(N_FRAMES)
+    pb, tb, ib = b.frame_log(N_FRAMES)
+    assert same_bits(pa, pb) and list(ta) == list(tb) and list(ia) == list(ib)
+    assert np.array_equal(a.render_volume(0, 1, k, 0.075), b.render_volume(0, 1, k, 0.075))
+    assert np.array_equal(a.render_depth(), b.render_depth()) and np.array_equal(a.render_track(), b.render_track())
+    a.close(); b.close()
+
+
 def test_gating_rates(hip, kfmod, orc):
     """tracking_rate / integration_rate gating (cpp:927, 994) including the stale-reduction re-check."""
     s = util.small_stream(N_FRAMES)
