@@ -59,7 +59,7 @@ struct ControlArgs {
 // Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_kernels.hip, "side jobs"):
 // a range of 32x8 bilateral tiles or of 32x32 pyramid tiles.  All buffers belong to the other half of the double buffer.
 struct SideWork {
-    enum Kind { NONE = 0, BILATERAL = 1, PYRAMID = 2 };
+    enum Kind { NONE = 0, BILATERAL = 1, PYRAMID = 2, RAY_ORDER = 3 };
     int kind;
     unsigned first, count;            // tile range
     unsigned W, H;
@@ -76,6 +76,9 @@ struct SideWork {
     float4 *vertex[4], *normal[4];
     const float4 *stale_normal[4];
     M4 invK[4];
+    // RAY_ORDER (dispatch order of the next raycast, one block)
+    unsigned *ray_order, *ray_cost;
+    unsigned ray_tiles_x, ray_tiles_y;
 };
 
 namespace launch {
@@ -124,7 +127,13 @@ size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz);
 void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             const unsigned char *skip_flags, hipStream_t s);
+             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, hipStream_t s);
+// raycast dispatch order (most expensive screen tiles of the previous launch first): ray_tiles() entries each
+unsigned ray_tiles(unsigned W, unsigned H);
+void init_ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned n, hipStream_t s);
+void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s);   // sort as a launch of its own
+void ray_tile_grid(unsigned W, unsigned H, unsigned *tiles_x, unsigned *tiles_y);
+bool ray_reorder_enabled();
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s);
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,

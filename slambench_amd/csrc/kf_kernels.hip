@@ -12,6 +12,7 @@
 #include "kf_kernels.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace kf {
 
@@ -742,6 +743,61 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     __syncthreads();
 }
 
+// =====================================================================================
+// Dispatch order of the raycast tiles for the next frame (see k_raycast): counting sort, most expensive first, of each
+// tile's cost dilated over its eight neighbours (a silhouette ray that just misses an object marches four times longer
+// than its neighbour that hits it, and which tile holds it changes with every camera step).  Ties go in any order - the
+// order is a scheduling hint, never an input of the computation.  One 1024-thread block; `cost` holds n raw costs
+// (cleared here) followed by n sort keys.  Runs as a side block of the first ICP launch of the next frame, or alone.
+// =====================================================================================
+constexpr int RAY_COST_BUCKETS = 256;
+constexpr unsigned RAY_ORDER_LDS_TILES = 8192;     // costs of up to this many tiles are staged in LDS
+struct RayOrderShared { unsigned hist[RAY_COST_BUCKETS], scan[RAY_COST_BUCKETS], offs[RAY_COST_BUCKETS], cost[RAY_ORDER_LDS_TILES]; };
+
+__device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__restrict__ order, unsigned *__restrict__ cost,
+                                                unsigned tiles_x, unsigned tiles_y) {
+    const unsigned n = tiles_x * tiles_y, tid = threadIdx.x, nthr = blockDim.x;
+    unsigned *key = cost + n;
+    const bool staged = n <= RAY_ORDER_LDS_TILES;
+    for (unsigned i = tid; i < RAY_COST_BUCKETS; i += nthr) sh.hist[i] = 0;
+    if (staged) for (unsigned i = tid; i < n; i += nthr) sh.cost[i] = cost[i];
+    __syncthreads();
+    const unsigned *src = staged ? sh.cost : cost;
+    for (unsigned i = tid; i < n; i += nthr) {
+        const int tx = i % tiles_x, ty = i / tiles_x;
+        unsigned m = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = tx + dx, y = ty + dy;
+                if (x >= 0 && y >= 0 && x < (int)tiles_x && y < (int)tiles_y) { const unsigned c = src[x + y * tiles_x]; m = m > c ? m : c; }
+            }
+        const unsigned b = (m >> 2) < RAY_COST_BUCKETS - 1 ? (m >> 2) : RAY_COST_BUCKETS - 1;
+        key[i] = b;
+        atomicAdd(&sh.hist[b], 1u);
+    }
+    __syncthreads();
+    // offs[b] = number of tiles in buckets above b (inclusive scan of the reversed histogram, minus the own count)
+    if (tid < RAY_COST_BUCKETS) sh.scan[tid] = sh.hist[RAY_COST_BUCKETS - 1 - tid];
+    __syncthreads();
+    for (unsigned d = 1; d < RAY_COST_BUCKETS; d <<= 1) {
+        const unsigned v = (tid < RAY_COST_BUCKETS && tid >= d) ? sh.scan[tid - d] : 0u;
+        __syncthreads();
+        if (tid < RAY_COST_BUCKETS) sh.scan[tid] += v;
+        __syncthreads();
+    }
+    if (tid < RAY_COST_BUCKETS) sh.offs[RAY_COST_BUCKETS - 1 - tid] = sh.scan[tid] - sh.hist[RAY_COST_BUCKETS - 1 - tid];
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += nthr) {
+        order[atomicAdd(&sh.offs[key[i]], 1u)] = i;
+        cost[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ray_order(unsigned *__restrict__ order, unsigned *__restrict__ cost, unsigned tiles_x, unsigned tiles_y) {
+    __shared__ RayOrderShared sh;
+    ray_order_block(sh, order, cost, tiles_x, tiles_y);
+}
+
 struct IcpIterArgs {
     DevState *st;
     IcpState *iters;
@@ -755,6 +811,8 @@ struct IcpIterArgs {
     const float4 *refV, *refN;
     unsigned refW, refH;
     float icp_threshold, dist_threshold, normal_threshold;
+    unsigned *ray_order, *ray_cost;       // side block `nblocks` of a plain launch: raycast dispatch order (nullptr = none)
+    unsigned ray_tiles_x, ray_tiles_y;
 };
 
 __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs &a) {
@@ -795,6 +853,14 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(IcpIterArgs a) {
     __shared__ IcpShared sh;
     icp_iter_block(sh, a);
+}
+
+// plain iteration plus one side block that sorts the raycast tiles (first launch of a queued frame)
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_order(IcpIterArgs a) {
+    __shared__ IcpShared sh;
+    __shared__ RayOrderShared ro;
+    if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
+    ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y);
 }
 
 // ---- side jobs ----------------------------------------------------------------------------------------------------
@@ -1172,6 +1238,44 @@ __device__ __forceinline__ f3 grad(const VolView &v, f3 pos) {
     return scale3(mul3(g, cell), 0.5f * kShort2Float);
 }
 
+// The same gradient computed by the four adjacent lanes that marched the ray together (k_raycast<4>): each component is
+// a trilinear blend of four x-blended difference pairs, one per (y, z) corner - lane q = jy + 2*jz evaluates its corner's
+// pair (4 taps per component instead of 16), and the blend over y then z is two exchange-and-add steps that perform
+// exactly the additions of the nested expression above (a*(1-f) + b*f with the operands swapped on the odd lane, which
+// IEEE addition does not notice).  All four lanes return the full vector.  12 gathers per lane instead of 32 on one lane
+// with the other three idle.
+__device__ __forceinline__ f3 grad_quad(const VolView &v, f3 pos, int q) {
+    const Taps t = locate(v, pos);
+    const int jy = q & 1, jz = (q >> 1) & 1;
+    const int *lo = t.lo, *up = t.up;
+    const int ll0 = imin(imax(t.base[0] - 1, 0), v.sx - 1), uu0 = imax(imin(t.base[0] + 2, v.sx - 1), 0);
+    const int ll1 = imin(imax(t.base[1] - 1, 0), v.sy - 1), uu1 = imax(imin(t.base[1] + 2, v.sy - 1), 0);
+    const int ll2 = imin(imax(t.base[2] - 1, 0), v.sz - 1), uu2 = imax(imin(t.base[2] + 2, v.sz - 1), 0);
+    const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
+    const float wy = jy ? fy : 1 - fy, wz = jz ? fz : 1 - fz;
+    const int Y = jy ? up[1] : lo[1], Z = jz ? up[2] : lo[2];
+    // x: differences along x at corner (Y, Z)
+    float gx = (tap(v, up[0], Y, Z) - tap(v, ll0, Y, Z)) * (1 - fx) + (tap(v, uu0, Y, Z) - tap(v, lo[0], Y, Z)) * fx;
+    // y: low pair (up1 - ll1) on jy = 0, high pair (uu1 - lo1) on jy = 1, in plane Z
+    const int Yp = jy ? uu1 : up[1], Ym = jy ? lo[1] : ll1;
+    float gy = (tap(v, lo[0], Yp, Z) - tap(v, lo[0], Ym, Z)) * (1 - fx) + (tap(v, up[0], Yp, Z) - tap(v, up[0], Ym, Z)) * fx;
+    // z: low pair (up2 - ll2) on jz = 0, high pair (uu2 - lo2) on jz = 1, in row Y
+    const int Zp = jz ? uu2 : up[2], Zm = jz ? lo[2] : ll2;
+    float gz = (tap(v, lo[0], Y, Zp) - tap(v, lo[0], Y, Zm)) * (1 - fx) + (tap(v, up[0], Y, Zp) - tap(v, up[0], Y, Zm)) * fx;
+    gx *= wy; gy *= wy; gz *= wy;
+    gx += __shfl_xor(gx, 1, 64); gy += __shfl_xor(gy, 1, 64); gz += __shfl_xor(gz, 1, 64);
+    gx *= wz; gy *= wz; gz *= wz;
+    gx += __shfl_xor(gx, 2, 64); gy += __shfl_xor(gy, 2, 64); gz += __shfl_xor(gz, 2, 64);
+    const f3 cell = mk3(v.dim.x / v.sx, v.dim.y / v.sy, v.dim.z / v.sz);
+    return scale3(mul3(mk3(gx, gy, gz), cell), 0.5f * kShort2Float);
+}
+
+template <int Q>
+__device__ __forceinline__ f3 grad_group(const VolView &v, f3 pos) {
+    if constexpr (Q == 4) return grad_quad(v, pos, threadIdx.x & 3);
+    else return grad(v, pos);
+}
+
 // ---- exact empty-space skipping -------------------------------------------------------------------------
 // One byte per 8x8x8 brick, set by integrate when it stores a TSDF below kSkipShort (0.8118) into any voxel of the
 // brick dilated by (-1, +9) voxels per axis.  A march sample whose (approximately located) base voxel lies in an
@@ -1187,6 +1291,9 @@ struct SkipGrid {
     int nbx, nby, nbz;
     float kx, ky, kz;             // size / dim per axis
     int two_phase;                // loop shape (only with flags)
+    unsigned long long *trace;    // debugging (KFH_RAY_TRACE): per wave {start, end} of the 100 MHz wall clock, else nullptr
+    const unsigned *order;        // launch slot -> screen tile (most expensive tiles of the last frame first), or nullptr
+    unsigned *cost;               // per screen tile: march rounds of its longest ray, for the next frame's order
 };
 
 __device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const VolView &v, f3 pos) {
@@ -1217,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_build_skip_grid(unsigned char *__restri
 }
 
 __device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py, const M4 &view,
-                                           float nearPlane, float farPlane, float step, float largestep) {
+                                           float nearPlane, float farPlane, float step, float largestep, int &work) {
     const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
     const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
     const f3 invR = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -1258,6 +1365,7 @@ __device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg,
                 }
             } else {
                 for (; t < tfar; t += stepsize) {
+                    ++work;
                     const f3 p = add3(origin, scale3(dir, t));
                     if (sg.flags && brick_is_empty(sg, v, p)) { lazy = true; t_ft = t; continue; }
                     f_tt = interp(v, p);
@@ -1278,6 +1386,8 @@ __device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg,
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+
 // ---- group-cooperative ray march --------------------------------------------------------------------------
 // The kernel time of the one-ray-per-lane march is the longest ray's serial chain (measured: mean 36 samples per
 // ray, longest tile 136; 0.8 us per dependent sample => ~110 us, with most SIMDs idle after ~35 us).  Here Q
@@ -1289,7 +1399,7 @@ __device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg,
 template <int Q>
 __device__ __forceinline__ float4 cast_ray_group(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py,
                                                  const M4 &view, float nearPlane, float farPlane, float step,
-                                                 float largestep) {
+                                                 float largestep, int &work) {
     const int lane = threadIdx.x & 63;
     const int q = lane & (Q - 1), base = lane & ~(Q - 1);
     const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
@@ -1311,6 +1421,7 @@ __device__ __forceinline__ float4 cast_ray_group(const VolView &v, const SkipGri
     float f_t = 0.f, t_ft = t;
     bool first = true;
     while (true) {
+        work += Q;
         float tq = t;
 #pragma unroll
         for (int i = 0; i < Q - 1; ++i) tq = (i < q) ? tq + stepsize : tq;
@@ -1371,21 +1482,21 @@ __device__ __forceinline__ float4 cast_ray_group(const VolView &v, const SkipGri
 // Pixel mapping shared by raycast and renderVolume.  A wave marches 64/Q rays laid out as a small screen tile (8x8, 8x4,
 // 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a 256-thread block is 2x2 such tiles.
 template <int Q>
-__device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y) {
+__device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y, unsigned bx, unsigned by) {
     constexpr int R = 64 / Q;                         // rays per wave
     constexpr int RW = (Q == 1 || Q == 2) ? 8 : 4;    // tile width
     constexpr int RH = R / RW;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned r = lane / Q;
-    x = (blockIdx.x * 2 + (wave & 1)) * RW + (r % RW);
-    y = (blockIdx.y * 2 + (wave >> 1)) * RH + (r / RW);
+    x = (bx * 2 + (wave & 1)) * RW + (r % RW);
+    y = (by * 2 + (wave >> 1)) * RH + (r / RW);
 }
 
 template <int Q>
 __device__ __forceinline__ float4 march(const VolView &v, const SkipGrid &sg, unsigned x, unsigned y, const M4 &view,
-                                        float nearPlane, float farPlane, float step, float largestep) {
-    if (Q == 1) return cast_ray(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
-    return cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
+                                        float nearPlane, float farPlane, float step, float largestep, int &work) {
+    if (Q == 1) return cast_ray(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
+    return cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
 }
 
 // raycastKernel (cpp:726-757)
@@ -1395,25 +1506,47 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
                                                  unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
                                                  float farPlane, float step, float largestep, SkipGrid sg) {
     if (!rp->enabled) return;
+    const unsigned long long t_start = sg.trace ? wall_clock64() : 0ull;
+    // Launch slot -> screen tile.  Workgroups are dispatched in slot order and the launch ends with its slowest wave, so
+    // the tiles whose rays marched longest in the previous frame (grazing views along a surface: up to 4x the mean) go
+    // first instead of wherever the raster order puts them - often the last dispatch round (measured: 65 -> see
+    // profiles/r01_sweeps.md).  The order only decides WHEN a tile is computed.
+    const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned tile = sg.order ? sg.order[slot] : slot;
     unsigned x, y;
-    tile_pixel<Q>(x, y);
+    tile_pixel<Q>(x, y, tile % gridDim.x, tile / gridDim.x);
     if (x >= W || y >= H) return;     // uniform per ray group: all Q lanes share the pixel
     const M4 view = rp->view;
     VolView v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
-    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
-    if ((threadIdx.x & (Q - 1)) != 0) return;   // one lane of the group finishes the pixel
+    int work = 0;
+    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
+    if (sg.cost || sg.trace) {   // the longest march of the wave, kept per tile for the next frame's dispatch order
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) work = imax(work, __shfl_xor(work, off, 64));
+        if (sg.cost && (threadIdx.x & 63) == 0) atomicMax(sg.cost + tile, (unsigned)work);
+    }
+    if (sg.trace && (threadIdx.x & 63) == 0) {
+        const unsigned wave = slot * 4 + (threadIdx.x >> 6);
+        sg.trace[4 * wave] = t_start;
+        sg.trace[4 * wave + 1] = wall_clock64();
+        sg.trace[4 * wave + 2] = (unsigned long long)work;
+        sg.trace[4 * wave + 3] = tile;
+    }
+    const bool writer = (threadIdx.x & (Q - 1)) == 0;   // one lane of the group finishes the pixel
+    if (Q != 4 && !writer) return;
     const unsigned p = x + y * W;
-    if (hit.w > 0.0) {
+    if (hit.w > 0.0) {                                  // uniform over the lanes of a ray
+        const f3 n = grad_group<Q>(v, mk3(hit.x, hit.y, hit.z));
+        if (!writer) return;
         vertex[p] = make_float4(hit.x, hit.y, hit.z, 0.f);
-        const f3 n = grad(v, mk3(hit.x, hit.y, hit.z));
         if (length3(n) == 0) {
             reinterpret_cast<float *>(normal + p)[0] = kInvalid;
         } else {
             const f3 nn = normalize3(n);
             normal[p] = make_float4(nn.x, nn.y, nn.z, 0.f);
         }
-    } else {
+    } else if (writer) {
         vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         normal[p] = make_float4(kInvalid, 0.f, 0.f, 0.f);
     }
@@ -1427,17 +1560,19 @@ __global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out,
                                                        float nearPlane, float farPlane, float step, float largestep,
                                                        f3 light, f3 ambient, SkipGrid sg) {
     unsigned x, y;
-    tile_pixel<Q>(x, y);
+    tile_pixel<Q>(x, y, blockIdx.x, blockIdx.y);
     if (x >= W || y >= H) return;
     const M4 view = rp->view;
     VolView v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
-    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep);
-    if ((threadIdx.x & (Q - 1)) != 0) return;
+    int work = 0;
+    const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
+    const bool writer = (threadIdx.x & (Q - 1)) == 0;
+    if (Q != 4 && !writer) return;
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (hit.w > 0) {
         const f3 test = mk3(hit.x, hit.y, hit.z);
-        const f3 n = grad(v, test);
+        const f3 n = grad_group<Q>(v, test);
         if (length3(n) > 0) {
             const f3 diff = normalize3(sub3(light, test));
             const float dir = fmax_h(dot3(normalize3(n), diff), 0.f);
@@ -1446,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out,
             o = make_uchar4((unsigned char)col.x, (unsigned char)col.y, (unsigned char)col.z, 0);
         }
     }
-    out[x + y * W] = o;
+    if (writer) out[x + y * W] = o;
 }
 
 // renderDepthKernel (cpp:814-842) with the double-precision ramp of commons.h:86-147
@@ -1627,6 +1762,7 @@ static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *par
     a.it = it; a.level = level; a.prev_level = prev_level; a.prev_nblocks = prev_nblocks; a.nblocks = nblocks;
     a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
     a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
+    a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0;
     return a;
 }
 
@@ -1646,7 +1782,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
               float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s) {
-    const IcpIterArgs a = make_icp_args(st, iters, partials_prev, partials_out, result_map, it, level, prev_level, prev_nblocks,
+    IcpIterArgs a = make_icp_args(st, iters, partials_prev, partials_out, result_map, it, level, prev_level, prev_nblocks,
                                         nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
                                         normal_threshold);
     if (side && side->kind == SideWork::BILATERAL && side->count) {
@@ -1678,6 +1814,11 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         }
         return;
     }
+    if (side && side->kind == SideWork::RAY_ORDER) {
+        a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y;
+        k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a);
+        return;
+    }
     k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a);
 }
 
@@ -1703,6 +1844,8 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     g.kx = sx / dim.x; g.ky = sy / dim.y; g.kz = sz / dim.z;
     static const long tp = env_long("KFH_RAY_TWO_PHASE", 0, 1, 0);
     g.two_phase = (flags && tp) ? 1 : 0;
+    g.trace = nullptr;
+    g.order = nullptr; g.cost = nullptr;
     return g;
 }
 
@@ -1751,15 +1894,55 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             const unsigned char *skip_flags, hipStream_t s) {
+             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, hipStream_t s) {
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
-    const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
+    SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
+    if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
+    // debugging aid: KFH_RAY_TRACE=<file> dumps {start, end} cycle stamps of every wave of the 200th raycast launch
+    static const char *trace_path = getenv("KFH_RAY_TRACE");
+    static unsigned long long *trace_buf = nullptr;
+    static int trace_launch = 0;
+    const dim3 tg = ray_grid(ray_group(), W, H);
+    const size_t trace_n = (size_t)tg.x * tg.y * 4 * 4;
+    const bool tracing = trace_path && ++trace_launch == 200;
+    if (tracing && hipMalloc(&trace_buf, trace_n * sizeof(unsigned long long)) == hipSuccess) {
+        hipMemsetAsync(trace_buf, 0, trace_n * sizeof(unsigned long long), s);
+        sg.trace = trace_buf;
+    }
+    struct TraceDump {
+        hipStream_t s; const char *path; unsigned long long *buf; size_t n; bool on;
+        ~TraceDump() {
+            if (!on || !buf) return;
+            std::vector<unsigned long long> h(n);
+            hipStreamSynchronize(s);
+            hipMemcpy(h.data(), buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), n, f); fclose(f); }
+            hipFree(buf);
+        }
+    } dump{s, trace_path, trace_buf, trace_n, tracing && sg.trace};
     switch (ray_group()) {
     case 1: k_raycast<1><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
     case 2: k_raycast<2><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
     case 8: k_raycast<8><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
     default: k_raycast<4><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
     }
+}
+
+void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
+    const dim3 tg = ray_grid(ray_group(), W, H);
+    k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y);
+}
+void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_grid(ray_group(), W, H); *tx = g.x; *ty = g.y; }
+bool ray_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_RAY_REORDER"); return !(e && e[0] == '0'); }(); return on; }
+
+unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_grid(ray_group(), W, H); return g.x * g.y; }
+
+__global__ void k_iota(unsigned *p, unsigned n) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+}
+void init_ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned n, hipStream_t s) {
+    k_iota<<<(n + 255) / 256, 256, 0, s>>>(tile_order, n);
+    hipMemsetAsync(tile_cost, 0, (size_t)2 * n * sizeof(unsigned), s);
 }
 
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {

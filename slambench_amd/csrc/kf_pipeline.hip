@@ -79,6 +79,8 @@ struct kfh_context {
     int16_t *d_volume = nullptr;
     unsigned char *d_skip = nullptr;   // one byte per 8^3 brick: set once a TSDF below 0.81 was stored near it
     bool use_skip = true;
+    unsigned *d_ray_order = nullptr, *d_ray_cost = nullptr;   // raycast tile dispatch order / per-tile cost of the last launch
+    bool ray_order_stale = false;      // a raycast has left new costs that no sort has consumed yet
     DevState *d_state = nullptr;
     FrameLogEntry *d_log = nullptr;
     unsigned log_capacity = 8192;
@@ -327,6 +329,14 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                     fill_side_pyramid(c, *next, side, lo, hi - lo);
                     sp = &side;
                 }
+            if (!sp && it == 0 && c->ray_order_stale) {   // the raycast dispatch sort rides on the first launch
+                std::memset(&side, 0, sizeof side);
+                side.kind = SideWork::RAY_ORDER;
+                side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost;
+                launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
+                sp = &side;
+                c->ray_order_stale = false;
+            }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
                              dist_threshold, normal_threshold, sp, c->stream);
@@ -347,9 +357,15 @@ static void enqueue_integrate(kfh_context *c, float mu) {
 }
 
 static void enqueue_raycast(kfh_context *c, float mu) {
+    if (c->ray_order_stale) {   // no ICP launch took the sort along (untracked frame, phase calls): run it on its own
+        launch::ray_order(c->d_ray_order, c->d_ray_cost, c->W, c->H, c->stream);
+        c->ray_order_stale = false;
+    }
     prof_begin(c, KFH_PROF_RAYCAST);
     launch::raycast(c->d_vertex, c->d_normal, c->W, c->H, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
-                    &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->stream);
+                    &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->d_ray_order,
+                    c->d_ray_cost, c->stream);
+    c->ray_order_stale = launch::ray_reorder_enabled();
     prof_end(c, KFH_PROF_RAYCAST);
 }
 
@@ -489,6 +505,9 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
     ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
     ok &= HIP_TRY(hipMalloc(&c->d_skip, launch::skip_grid_bytes(res[0], res[1], res[2])));
+    ok &= HIP_TRY(hipMalloc(&c->d_ray_order, (size_t)launch::ray_tiles(width, height) * sizeof(unsigned)));
+    ok &= HIP_TRY(hipMalloc(&c->d_ray_cost, (size_t)2 * launch::ray_tiles(width, height) * sizeof(unsigned)));   // raw costs + sort keys
+    if (ok) launch::init_ray_order(c->d_ray_order, c->d_ray_cost, launch::ray_tiles(width, height), c->stream);
     { const char *e = getenv("KFH_NO_SKIP"); c->use_skip = !(e && e[0] == '1'); }
     ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
     ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
@@ -558,7 +577,7 @@ void kfh_destroy(kfh_context *c) {
     for (float *p : c->alt_scaled) hipFree(p);
     for (float4 *p : c->alt_inV) hipFree(p);
     for (float4 *p : c->alt_inN) hipFree(p);
-    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip);
+    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip); hipFree(c->d_ray_order); hipFree(c->d_ray_cost);
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
     for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
@@ -1028,7 +1047,7 @@ void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const
     RayParams *d = upload_ray(view16, s);
     if (!d) return;
     launch::raycast(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), w, h, vol, size[0], size[1], size[2],
-                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, nullptr, s);
+                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, nullptr, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 
