@@ -16,7 +16,7 @@ for f in np.linspace(0.1, 1.0, 10):
     t = span * f
     print("t=%5.1f us  running %5d  finished %5d  not started %5d" % (t, int(((st <= t) & (en > t)).sum()), int((en <= t).sum()), int((st > t).sum())))
 late = np.argsort(en)[-8:]
-print("last finishers: " + "; ".join("slot-wave %d tile %d work %d start %.1f dur %.1f" % (idx[i], a[i, 3], a[i, 2], st[i], dur[i]) for i in late))
+print("last finishers: " + "; ".join("wave %d id %d work %d start %.1f dur %.1f" % (idx[i], a[i, 3], a[i, 2], st[i], dur[i]) for i in late))
 w = a[:, 2].astype(np.float64)
 print("work (rounds*Q of the wave's longest ray): mean %.1f p90 %.0f p99 %.0f max %.0f; corr(work, lifetime) %.3f" % (w.mean(), *np.percentile(w, [90, 99]), w.max(), np.corrcoef(w, dur)[0, 1]))
 for lo, hi in ((0, 24), (24, 40), (40, 60), (60, 90), (90, 400)):

@@ -12,6 +12,7 @@
 #include "kf_kernels.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace kf {
@@ -383,18 +384,14 @@ constexpr unsigned TR_MAX_BLOCKS = 2048;
 
 struct PixelTrack { int result; float error; float J[6]; };
 
-__device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, const float4 *__restrict__ inV,
-                                                  const float4 *__restrict__ inN, unsigned inW,
-                                                  const float4 *__restrict__ refV, const float4 *__restrict__ refN,
-                                                  unsigned refW, unsigned refH, const M4 &T, const M4 &view,
-                                                  int have_reference, float dist_threshold, float normal_threshold) {
+__device__ __forceinline__ PixelTrack track_fetched(float4 n4, float4 v4, const float4 *__restrict__ refV,
+                                                    const float4 *__restrict__ refN, unsigned refW, unsigned refH, const M4 &T,
+                                                    const M4 &view, int have_reference, float dist_threshold,
+                                                    float normal_threshold) {
     PixelTrack r;
     r.error = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.J[i] = 0.f;
-    // both input maps are fetched before the first test so the two loads are in flight together
-    const float4 n4 = inN[px + py * inW];
-    const float4 v4 = inV[px + py * inW];
     if (n4.x == kInvalid) { r.result = -1; return r; }
     const f3 pv = xform(T, mk3(v4.x, v4.y, v4.z));
     unsigned rx = 0, ry = 0;
@@ -418,6 +415,17 @@ __device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, cons
     const f3 c = cross3(pv, n_ref);
     r.J[3] = c.x; r.J[4] = c.y; r.J[5] = c.z;
     return r;
+}
+
+__device__ __forceinline__ PixelTrack track_pixel(unsigned px, unsigned py, const float4 *__restrict__ inV,
+                                                  const float4 *__restrict__ inN, unsigned inW,
+                                                  const float4 *__restrict__ refV, const float4 *__restrict__ refN,
+                                                  unsigned refW, unsigned refH, const M4 &T, const M4 &view,
+                                                  int have_reference, float dist_threshold, float normal_threshold) {
+    // both input maps are fetched before the first test so the two loads are in flight together
+    const float4 n4 = inN[px + py * inW];
+    const float4 v4 = inV[px + py * inW];
+    return track_fetched(n4, v4, refV, refN, refW, refH, T, view, have_reference, dist_threshold, normal_threshold);
 }
 
 __device__ __forceinline__ void accumulate(float (&acc)[32], int result, float e, const float (&J)[6]) {
@@ -698,9 +706,17 @@ struct IcpShared {
 };
 
 // Brings `sh` to the state entering iteration `it`: pose and flags after the update of iteration it-1.
+#define ICP_STAMP(i) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[i] = __builtin_readcyclecounter(); } while (0)
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// `after_handover` runs once the state of the previous launch is in LDS (sh.done is valid) and before the sums and the
+// solve: the place to start loads whose latency the prologue can hide.
+template <class F = NoPrefetch>
 __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *__restrict__ iters,
                                             const float *__restrict__ partials_prev, int it, int prev_level,
-                                            unsigned prev_nblocks, float icp_threshold, bool writer) {
+                                            unsigned prev_nblocks, float icp_threshold, bool writer,
+                                            unsigned long long *trace = nullptr, F after_handover = F()) {
+    ICP_STAMP(0);
     if (threadIdx.x == 0) {
         if (it == 0) {
             sh.pose = st->pose;
@@ -714,6 +730,8 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
         }
     }
     __syncthreads();
+    ICP_STAMP(1);
+    after_handover();
     if (!sh.prev_executed) return;   // uniform: the previous iteration was skipped, nothing to solve
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     constexpr int G = ICP_THREADS / 32;
@@ -729,6 +747,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
         if (writer) st->reduction[threadIdx.x] = v;
     }
     __syncthreads();
+    ICP_STAMP(2);
     if (threadIdx.x == 0) {
         M4 pose = sh.pose;
         bool fast = true;
@@ -740,6 +759,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
             if (!fast) st->solve_fallbacks += 1;
         }
     }
+    ICP_STAMP(3);
     __syncthreads();
 }
 
@@ -811,6 +831,7 @@ struct IcpIterArgs {
     const float4 *refV, *refN;
     unsigned refW, refH;
     float icp_threshold, dist_threshold, normal_threshold;
+    unsigned long long *trace;            // debugging (KFH_ICP_TRACE): stamps of block 0 / thread 0, else nullptr
     unsigned *ray_order, *ray_cost;       // side block `nblocks` of a plain launch: raycast dispatch order (nullptr = none)
     unsigned ray_tiles_x, ray_tiles_y;
 };
@@ -819,7 +840,8 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
     DevState *__restrict__ st = a.st;
     IcpState *__restrict__ iters = a.iters;
     const bool writer = blockIdx.x == 0;
-    icp_advance(sh, st, iters, a.partials_prev, a.it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer);
+    unsigned long long *trace = a.trace;
+    icp_advance(sh, st, iters, a.partials_prev, a.it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer, trace);
     if (threadIdx.x == 0) {
         sh.executed = sh.done[a.level] ? 0 : 1;
         if (writer) {
@@ -830,6 +852,7 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
         }
     }
     __syncthreads();
+    ICP_STAMP(4);
     if (!sh.executed) return;
     const M4 T = sh.pose;
     const M4 view = st->track.view;
@@ -847,7 +870,9 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
         result_map[px + py * a.refW] = r.result;   // full-resolution row stride on every level (cpp:512)
         accumulate(acc, r.result, r.error, r.J);
     }
+    ICP_STAMP(5);
     block_reduce_store<ICP_THREADS>(acc, a.partials_out + (size_t)blockIdx.x * 32);
+    ICP_STAMP(6);
 }
 
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(IcpIterArgs a) {
@@ -986,8 +1011,10 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
                                                    unsigned zchunk, unsigned long long *__restrict__ updated_total,
-                                                   unsigned char *__restrict__ skip_flags, int dbg) {
+                                                   unsigned char *__restrict__ skip_flags, int dbg,
+                                                   unsigned long long *__restrict__ trace) {
     if (!ip->enabled) return;
+    const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     unsigned updated = 0;
     if (x < sx && y < sy) {
@@ -1116,6 +1143,11 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             }
         }
     }
+    if (trace && threadIdx.x == 0) {   // debugging (KFH_INTEGRATE_TRACE): per wave {start, end, voxels updated by lane 0, block}
+        const unsigned blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned wave = blk * 4 + threadIdx.y;
+        trace[4 * wave] = t_start; trace[4 * wave + 1] = wall_clock64(); trace[4 * wave + 2] = updated; trace[4 * wave + 3] = blk;
+    }
     // instrumentation (U = voxels that passed all four tests): one atomic per wave
     if (updated_total) {
 #pragma unroll
@@ -1127,31 +1159,65 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
 // =====================================================================================
 // Volume sampling (commons.h:191-301) and the ray march (cpp:674-725)
 // =====================================================================================
-struct VolView {
+// Division by a launch-wide constant (the volume dimension in commons.h:193-195) without the 11-instruction IEEE
+// sequence: with r = RN(1/d), q = a*r followed by one residual correction (e = fma(-d, q, a); q = fma(e, r, q)) is the
+// correctly rounded quotient for every numerator the march can produce.  That is not taken on trust: the first time a
+// divisor is seen, k_verify_div compares the short form with the IEEE quotient for EVERY float in [2^-100, 2^24) - 1.04e9
+// values; negative numerators follow by symmetry, smaller ones give +-tiny either way, which the following "- 0.5f"
+// absorbs, and pos*size stays below 2^24 for every volume the launchers accept - and one mismatch keeps the IEEE division
+// for that volume (template flag FD of the view).
+__device__ __forceinline__ float div_by_const(float a, float d, float r) {
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+}
+
+__global__ __launch_bounds__(256) void k_verify_div(float d, float r, unsigned long long *mismatches) {
+    const unsigned long long n = 124ull << 23;   // biased exponents 27..150
+    unsigned bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float a = __builtin_bit_cast(float, (27u << 23) + (unsigned)i);
+        bad += (__builtin_bit_cast(unsigned, a / d) != __builtin_bit_cast(unsigned, div_by_const(a, d, r))) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+template <int FD>
+struct VolViewT {
+    static constexpr int kFastDiv = FD;
     const short2 *data;
     int sx, sy, sz;
     f3 dim;
+    f3 rdim;       // RN(1 / dim), read only when FD = 1
     size_t plane;
 };
 
 // Voxel addressing in 32 bits: the launchers refuse volumes above 2^30 voxels, so the BYTE offset of a voxel fits an
 // unsigned 32-bit register and the load can use the scalar-base + 32-bit vector-offset form (two integer mads per tap
 // instead of two 64-bit multiply-adds).
-__device__ __forceinline__ unsigned voxel_byte_offset(const VolView &v, int x, int y, int z) {
+template <class V>
+__device__ __forceinline__ unsigned voxel_byte_offset(const V &v, int x, int y, int z) {
     return ((unsigned)x + (unsigned)y * (unsigned)v.sx + (unsigned)z * (unsigned)v.plane) * 4u;
 }
 
-__device__ __forceinline__ float tap(const VolView &v, int x, int y, int z) {
+template <class V>
+__device__ __forceinline__ float tap(const V &v, int x, int y, int z) {
     const short2 *p = reinterpret_cast<const short2 *>(reinterpret_cast<const char *>(v.data) + voxel_byte_offset(v, x, y, z));
     return (float)p->x;   // commons.h:172-174
 }
 
 struct Taps { int lo[3], up[3]; f3 fr; int base[3]; };
 
-__device__ __forceinline__ Taps locate(const VolView &v, f3 pos) {
+template <class V>
+__device__ __forceinline__ Taps locate(const V &v, f3 pos) {
     Taps t;
-    const float sp0 = (pos.x * v.sx / v.dim.x) - 0.5f, sp1 = (pos.y * v.sy / v.dim.y) - 0.5f,
-                sp2 = (pos.z * v.sz / v.dim.z) - 0.5f;
+    float sp0, sp1, sp2;
+    if constexpr (V::kFastDiv) {
+        sp0 = div_by_const(pos.x * v.sx, v.dim.x, v.rdim.x) - 0.5f;
+        sp1 = div_by_const(pos.y * v.sy, v.dim.y, v.rdim.y) - 0.5f;
+        sp2 = div_by_const(pos.z * v.sz, v.dim.z, v.rdim.z) - 0.5f;
+    } else {
+        sp0 = (pos.x * v.sx / v.dim.x) - 0.5f; sp1 = (pos.y * v.sy / v.dim.y) - 0.5f; sp2 = (pos.z * v.sz / v.dim.z) - 0.5f;
+    }
     const float f0 = floorf(sp0), f1 = floorf(sp1), f2 = floorf(sp2);
     t.base[0] = (int)f0; t.base[1] = (int)f1; t.base[2] = (int)f2;
     t.fr = mk3(sp0 - f0, sp1 - f1, sp2 - f2);
@@ -1172,7 +1238,8 @@ __device__ __forceinline__ Taps locate(const VolView &v, f3 pos) {
 // address path, not by bytes).  The values are the same shorts, so the result is bit-identical.
 struct __attribute__((packed, aligned(4))) VoxelPair { int a, b; };
 
-__device__ __forceinline__ void tap_pair(const VolView &v, int p, int y, int z, bool lo_first, bool up_first, float &vlo,
+template <class V>
+__device__ __forceinline__ void tap_pair(const V &v, int p, int y, int z, bool lo_first, bool up_first, float &vlo,
                                          float &vup) {
     const VoxelPair q = *reinterpret_cast<const VoxelPair *>(reinterpret_cast<const char *>(v.data) + voxel_byte_offset(v, p, y, z));
     const float first = (float)(short)q.a, second = (float)(short)q.b;   // .x is the low half of each short2
@@ -1180,7 +1247,8 @@ __device__ __forceinline__ void tap_pair(const VolView &v, int p, int y, int z, 
     vup = up_first ? first : second;
 }
 
-__device__ __forceinline__ float interp(const VolView &v, f3 pos) {
+template <class V>
+__device__ __forceinline__ float interp(const V &v, f3 pos) {
     const Taps t = locate(v, pos);
     const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
     const int p = imax(imin(t.lo[0], v.sx - 2), 0);
@@ -1198,7 +1266,8 @@ __device__ __forceinline__ float interp(const VolView &v, f3 pos) {
 // Central differences blended trilinearly (commons.h:215-301).  For axis A the four planes are
 // ll = max(base-1,0), lo = max(base,0), up = min(base+1,size-1), uu = min(base+2,size-1); the low
 // difference is v(up)-v(ll) and the high one v(uu)-v(lo).
-__device__ __forceinline__ f3 grad(const VolView &v, f3 pos) {
+template <class V>
+__device__ __forceinline__ f3 grad(const V &v, f3 pos) {
     const Taps t = locate(v, pos);
     const int s[3] = {v.sx, v.sy, v.sz};
     int ll[3], uu[3];
@@ -1244,7 +1313,8 @@ __device__ __forceinline__ f3 grad(const VolView &v, f3 pos) {
 // exactly the additions of the nested expression above (a*(1-f) + b*f with the operands swapped on the odd lane, which
 // IEEE addition does not notice).  All four lanes return the full vector.  12 gathers per lane instead of 32 on one lane
 // with the other three idle.
-__device__ __forceinline__ f3 grad_quad(const VolView &v, f3 pos, int q) {
+template <class V>
+__device__ __forceinline__ f3 grad_quad(const V &v, f3 pos, int q) {
     const Taps t = locate(v, pos);
     const int jy = q & 1, jz = (q >> 1) & 1;
     const int *lo = t.lo, *up = t.up;
@@ -1270,8 +1340,8 @@ __device__ __forceinline__ f3 grad_quad(const VolView &v, f3 pos, int q) {
     return scale3(mul3(mk3(gx, gy, gz), cell), 0.5f * kShort2Float);
 }
 
-template <int Q>
-__device__ __forceinline__ f3 grad_group(const VolView &v, f3 pos) {
+template <int Q, class V>
+__device__ __forceinline__ f3 grad_group(const V &v, f3 pos) {
     if constexpr (Q == 4) return grad_quad(v, pos, threadIdx.x & 3);
     else return grad(v, pos);
 }
@@ -1296,7 +1366,8 @@ struct SkipGrid {
     unsigned *cost;               // per screen tile: march rounds of its longest ray, for the next frame's order
 };
 
-__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const VolView &v, f3 pos) {
+template <class V>
+__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const V &v, f3 pos) {
     const int vx = (int)floorf(pos.x * g.kx - 0.5f), vy = (int)floorf(pos.y * g.ky - 0.5f), vz = (int)floorf(pos.z * g.kz - 0.5f);
     const int bx = imin(imax(vx, 0), v.sx - 1) >> 3, by = imin(imax(vy, 0), v.sy - 1) >> 3, bz = imin(imax(vz, 0), v.sz - 1) >> 3;
     return g.flags[bx + g.nbx * (by + g.nby * bz)] == 0;
@@ -1323,7 +1394,8 @@ __global__ __launch_bounds__(256) void k_build_skip_grid(unsigned char *__restri
     }
 }
 
-__device__ __forceinline__ float4 cast_ray(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py, const M4 &view,
+template <class V>
+__device__ __forceinline__ float4 cast_ray(const V &v, const SkipGrid &sg, unsigned px, unsigned py, const M4 &view,
                                            float nearPlane, float farPlane, float step, float largestep, int &work) {
     const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
     const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
@@ -1396,8 +1468,8 @@ __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b
 // the reference loop would do something other than "continue" (leave the volume, cross zero, or switch from the large to
 // the small step, cpp:709-716) decides the ray's next state.  Samples past that lane are discarded.  The chain per ray
 // shrinks Q-fold and the frame exposes Q times more waves; decisions and bits are those of the serial loop.
-template <int Q>
-__device__ __forceinline__ float4 cast_ray_group(const VolView &v, const SkipGrid &sg, unsigned px, unsigned py,
+template <int Q, class V>
+__device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg, unsigned px, unsigned py,
                                                  const M4 &view, float nearPlane, float farPlane, float step,
                                                  float largestep, int &work) {
     const int lane = threadIdx.x & 63;
@@ -1492,19 +1564,19 @@ __device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y, unsigned bx
     y = (by * 2 + (wave >> 1)) * RH + (r / RW);
 }
 
-template <int Q>
-__device__ __forceinline__ float4 march(const VolView &v, const SkipGrid &sg, unsigned x, unsigned y, const M4 &view,
+template <int Q, class V>
+__device__ __forceinline__ float4 march(const V &v, const SkipGrid &sg, unsigned x, unsigned y, const M4 &view,
                                         float nearPlane, float farPlane, float step, float largestep, int &work) {
     if (Q == 1) return cast_ray(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
     return cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
 }
 
 // raycastKernel (cpp:726-757)
-template <int Q>
+template <int Q, int FD>
 __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal, unsigned W,
                                                  unsigned H, const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                  unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
-                                                 float farPlane, float step, float largestep, SkipGrid sg) {
+                                                 float farPlane, float step, float largestep, SkipGrid sg, f3 rdim) {
     if (!rp->enabled) return;
     const unsigned long long t_start = sg.trace ? wall_clock64() : 0ull;
     // Launch slot -> screen tile.  Workgroups are dispatched in slot order and the launch ends with its slowest wave, so
@@ -1517,8 +1589,8 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     tile_pixel<Q>(x, y, tile % gridDim.x, tile / gridDim.x);
     if (x >= W || y >= H) return;     // uniform per ray group: all Q lanes share the pixel
     const M4 view = rp->view;
-    VolView v;
-    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
+    VolViewT<FD> v;
+    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.rdim = rdim; v.plane = (size_t)sx * sy;
     int work = 0;
     const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
     if (sg.cost || sg.trace) {   // the longest march of the wave, kept per tile for the next frame's dispatch order
@@ -1553,18 +1625,18 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
 }
 
 // renderVolumeKernel (cpp:880-913)
-template <int Q>
+template <int Q, int FD>
 __global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
                                                        const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                        unsigned sz, f3 dim, const RayParams *__restrict__ rp,
                                                        float nearPlane, float farPlane, float step, float largestep,
-                                                       f3 light, f3 ambient, SkipGrid sg) {
+                                                       f3 light, f3 ambient, SkipGrid sg, f3 rdim) {
     unsigned x, y;
     tile_pixel<Q>(x, y, blockIdx.x, blockIdx.y);
     if (x >= W || y >= H) return;
     const M4 view = rp->view;
-    VolView v;
-    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.plane = (size_t)sx * sy;
+    VolViewT<FD> v;
+    v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.rdim = rdim; v.plane = (size_t)sx * sy;
     int work = 0;
     const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
     const bool writer = (threadIdx.x & (Q - 1)) == 0;
@@ -1663,6 +1735,33 @@ unsigned track_blocks(unsigned w, unsigned h) {
 }
 
 unsigned track_blocks_max() { return TR_MAX_BLOCKS; }
+
+// Debugging aid shared by the traced kernels: <ENV>=<file> makes the 200th launch write four 64-bit words per wave
+// ({start, end} on the 100 MHz wall clock and two kernel-specific values) and dumps them (profiles/ray_trace.py).
+struct WaveTrace {
+    const char *path = nullptr;
+    int launches = 0;
+    unsigned long long *buf = nullptr;
+    size_t words = 0;
+    hipStream_t stream = nullptr;
+    explicit WaveTrace(const char *env) : path(getenv(env)) {}
+    unsigned long long *arm(size_t waves, hipStream_t s) {     // device buffer for this launch, or nullptr
+        if (!path || ++launches != 200) return nullptr;
+        words = waves * 4; stream = s;
+        if (hipMalloc(&buf, words * sizeof(unsigned long long)) != hipSuccess) { buf = nullptr; return nullptr; }
+        hipMemsetAsync(buf, 0, words * sizeof(unsigned long long), s);
+        return buf;
+    }
+    void dump() {
+        if (!buf) return;
+        std::vector<unsigned long long> h(words);
+        hipStreamSynchronize(stream);
+        hipMemcpy(h.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), words, f); fclose(f); }
+        hipFree(buf);
+        buf = nullptr;
+    }
+};
 
 unsigned icp_blocks(unsigned w, unsigned h) {
     // default 256 blocks of 1024 threads (one per CU, ~1.2 pixels per thread at 640x480); KFH_ICP_BLOCKS overrides
@@ -1763,6 +1862,7 @@ static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *par
     a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
     a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
     a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0;
+    a.trace = nullptr;
     return a;
 }
 
@@ -1814,6 +1914,9 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         }
         return;
     }
+    static WaveTrace wt("KFH_ICP_TRACE");
+    static const int trace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 10; }();
+    if (it == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); wt.dump(); return; } }
     if (side && side->kind == SideWork::RAY_ORDER) {
         a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y;
         k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a);
@@ -1856,6 +1959,40 @@ void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsi
     k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3);
 }
 
+// Has the reciprocal form of a / d been verified for this divisor on this device (see k_verify_div)?  Cached; the check
+// takes a few milliseconds once per context (kfh_create calls prepare_volume_division).  KFH_EXACT_DIV=0 keeps IEEE.
+static bool verified_divisor(float d, hipStream_t s) {
+    struct Entry { int dev; float d; bool ok; };
+    static std::vector<Entry> cache;
+    static std::mutex mu;
+    static const bool allow = [] { const char *e = getenv("KFH_EXACT_DIV"); return !(e && e[0] == '0'); }();
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry &e : cache) if (e.dev == dev && e.d == d) return e.ok;
+    bool ok = false;
+    if (allow && d > 0x1p-10f && d < 0x1p10f) {
+        unsigned long long *dm = nullptr;
+        if (hipMalloc(&dm, sizeof *dm) == hipSuccess) {
+            unsigned long long h = 1;
+            hipMemsetAsync(dm, 0, sizeof *dm, s);
+            k_verify_div<<<8192, 256, 0, s>>>(d, 1.0f / d, dm);
+            if (hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) ok = h == 0;
+            hipFree(dm);
+        }
+    }
+    cache.push_back(Entry{dev, d, ok});
+    return ok;
+}
+
+// all three axes verified and every numerator pos * size below 2^24
+static bool fast_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
+    if (!((double)dim.x * sx < 8.0e6 && (double)dim.y * sy < 8.0e6 && (double)dim.z * sz < 8.0e6)) return false;
+    return verified_divisor(dim.x, s) && verified_divisor(dim.y, s) && verified_divisor(dim.z, s);
+}
+
+void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) { (void)fast_division(dim, sx, sy, sz, s); }
+
 static int ray_group() {   // lanes per ray (KFH_RAY_GROUP = 1, 2, 4, 8)
     static const long g = env_long("KFH_RAY_GROUP", 1, 8, 4);
     return (g == 1 || g == 2 || g == 8) ? (int)g : 4;
@@ -1877,7 +2014,7 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
                hipStream_t s) {
     // enough z-chunks to put >= ~8192 waves in flight on 256 CUs; each chunk replays its z0 additions
     static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
-    static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 8, 8);
+    static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
     static const int dbg = (int)env_long("KFH_INTEGRATE_DBG", 0, 7, 0);
     const unsigned waves_xy = ((sx + 63) / 64) * sy;
     unsigned nchunks = chunks_env ? (unsigned)chunks_env : (8192 + waves_xy - 1) / waves_xy;
@@ -1887,9 +2024,13 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
     const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);
-    if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
-    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
-    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg);
+    static WaveTrace wt("KFH_INTEGRATE_TRACE");
+    unsigned long long *trace = wt.arm((size_t)grid.x * grid.y * grid.z * 4, s);
+    if (batch_env >= 16) k_integrate<16><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
+    else if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
+    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
+    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
+    wt.dump();
 }
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
@@ -1898,34 +2039,26 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
     SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
     if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
-    // debugging aid: KFH_RAY_TRACE=<file> dumps {start, end} cycle stamps of every wave of the 200th raycast launch
-    static const char *trace_path = getenv("KFH_RAY_TRACE");
-    static unsigned long long *trace_buf = nullptr;
-    static int trace_launch = 0;
+    static WaveTrace wt("KFH_RAY_TRACE");
     const dim3 tg = ray_grid(ray_group(), W, H);
-    const size_t trace_n = (size_t)tg.x * tg.y * 4 * 4;
-    const bool tracing = trace_path && ++trace_launch == 200;
-    if (tracing && hipMalloc(&trace_buf, trace_n * sizeof(unsigned long long)) == hipSuccess) {
-        hipMemsetAsync(trace_buf, 0, trace_n * sizeof(unsigned long long), s);
-        sg.trace = trace_buf;
-    }
-    struct TraceDump {
-        hipStream_t s; const char *path; unsigned long long *buf; size_t n; bool on;
-        ~TraceDump() {
-            if (!on || !buf) return;
-            std::vector<unsigned long long> h(n);
-            hipStreamSynchronize(s);
-            hipMemcpy(h.data(), buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), n, f); fclose(f); }
-            hipFree(buf);
+    sg.trace = wt.arm((size_t)tg.x * tg.y * 4, s);
+    const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
+    if (fast_division(dim, sx, sy, sz, s)) {
+        switch (ray_group()) {
+        case 1: k_raycast<1, 1><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 1><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 1><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 1><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
         }
-    } dump{s, trace_path, trace_buf, trace_n, tracing && sg.trace};
-    switch (ray_group()) {
-    case 1: k_raycast<1><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
-    case 2: k_raycast<2><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
-    case 8: k_raycast<8><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
-    default: k_raycast<4><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg); break;
+    } else {
+        switch (ray_group()) {
+        case 1: k_raycast<1, 0><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 0><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 0><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 0><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        }
     }
+    wt.dump();
 }
 
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
@@ -1958,11 +2091,21 @@ void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsi
                    const unsigned char *skip_flags, hipStream_t s) {
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
     const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
-    switch (ray_group()) {
-    case 1: k_render_volume<1><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
-    case 2: k_render_volume<2><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
-    case 8: k_render_volume<8><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
-    default: k_render_volume<4><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg); break;
+    const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
+    if (fast_division(dim, sx, sy, sz, s)) {
+        switch (ray_group()) {
+        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        default: k_render_volume<4, 1><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        }
+    } else {
+        switch (ray_group()) {
+        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        default: k_render_volume<4, 0><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        }
     }
 }
 

@@ -147,10 +147,24 @@ KF_HD M4 se3_exp_to_m4(const double mu[6]) {
             A = 1.0 - theta_sq * C;
             B = 0.5 - 0.25 * one_6th * theta_sq;
         } else {
-            const double inv_theta = 1.0 / theta;
-            A = sin(theta) * inv_theta;
-            B = (1 - cos(theta)) * (inv_theta * inv_theta);
-            C = (1 - A) * (inv_theta * inv_theta);
+            if (theta_sq < 0.25) {
+                // sin(t)/t, (1 - cos t)/t^2 and (1 - sin(t)/t)/t^2 from their alternating series in s = t^2 (nine terms:
+                // the first neglected one is below 1e-22 for s < 0.25), i.e. to a couple of ulps of double - the values
+                // are rounded to float below.  An ICP update is a rotation of a few milliradians; the library sin/cos
+                // pair costs this single thread ~1500 dependent cycles per iteration, the three Horner chains ~300.
+                const double s = theta_sq;
+                A = 1.0 - s * (1.0 / 6.0) * (1.0 - s * (1.0 / 20.0) * (1.0 - s * (1.0 / 42.0) * (1.0 - s * (1.0 / 72.0) * (1.0 - s * (1.0 / 110.0) *
+                    (1.0 - s * (1.0 / 156.0) * (1.0 - s * (1.0 / 210.0) * (1.0 - s * (1.0 / 272.0))))))));
+                B = 0.5 * (1.0 - s * (1.0 / 12.0) * (1.0 - s * (1.0 / 30.0) * (1.0 - s * (1.0 / 56.0) * (1.0 - s * (1.0 / 90.0) * (1.0 - s * (1.0 / 132.0) *
+                    (1.0 - s * (1.0 / 182.0) * (1.0 - s * (1.0 / 240.0) * (1.0 - s * (1.0 / 306.0)))))))));
+                C = one_6th * (1.0 - s * (1.0 / 20.0) * (1.0 - s * (1.0 / 42.0) * (1.0 - s * (1.0 / 72.0) * (1.0 - s * (1.0 / 110.0) * (1.0 - s * (1.0 / 156.0) *
+                    (1.0 - s * (1.0 / 210.0) * (1.0 - s * (1.0 / 272.0) * (1.0 - s * (1.0 / 342.0)))))))));
+            } else {
+                const double inv_theta = 1.0 / theta;
+                A = sin(theta) * inv_theta;
+                B = (1 - cos(theta)) * (inv_theta * inv_theta);
+                C = (1 - A) * (inv_theta * inv_theta);
+            }
         }
         const double d0 = w1 * c2 - w2 * c1, d1 = w2 * c0 - w0 * c2, d2 = w0 * c1 - w1 * c0;
         t0 = v0 + B * c0 + C * d0; t1 = v1 + B * c1 + C * d1; t2 = v2 + B * c2 + C * d2;
@@ -236,11 +250,9 @@ __host__ __device__ inline void solve6(const float *vals, double x[6]) {
 
 // Fast path of the same solve.  When C is comfortably positive definite the pseudo-inverse of
 // commons.h:403 keeps every singular value, so x = C^-1 b, and an LDL^T factorisation (6 divisions, no
-// square roots, no iteration) gives it to the same ~1e-12.  The factorisation certifies its own use:
-// cond_2(C) <= |C|_F * |C^-1|_F, so when that product is below 5e5 no singular value can fall under the
-// reference's max/1e6 cut-off and the two solves agree.  Otherwise (the all-zero system of frames 0-3,
-// degenerate geometry) the caller falls back to solve6.  The Frobenius bound over-estimates the
-// condition number by at most 6x, so every system with cond < 8e4 takes the fast path.
+// square roots, no iteration) followed by two triangular substitutions gives it to the same ~1e-12.  The
+// factorisation certifies its own use (see the bound below); otherwise (the all-zero system of frames 0-3,
+// degenerate or badly scaled geometry) the caller falls back to solve6.
 __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
     double L[6][6], d[6], b[6];
     double c_f2 = 0.0, tr = 0.0;
@@ -260,6 +272,7 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
     if (!(tr > 0.0)) return false;
     const double tiny = tr * 1e-9;
     // in-place LDL^T: L[i][j] (i > j) becomes the unit-lower factor, d the diagonal
+    double invd[6], dmin = 1e300;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double dj = L[j][j];
@@ -267,7 +280,9 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
         for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * d[k];
         if (!(dj > tiny)) return false;
         d[j] = dj;
+        dmin = dj < dmin ? dj : dmin;
         const double inv = 1.0 / dj;
+        invd[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double v = L[i][j];
@@ -277,36 +292,39 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
         }
     }
     // M = L^-1 (unit lower triangular), column by column
-    double M[6][6], invd[6];
+    double M[6][6], m_f2 = 6.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        invd[c] = 1.0 / d[c];
+    for (int c = 0; c < 6; ++c)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            if (r < c) { M[r][c] = 0.0; continue; }
-            if (r == c) { M[r][c] = 1.0; continue; }
-            double v = 0.0;
+        for (int r = c + 1; r < 6; ++r) {
+            double v = -L[r][c];
 #pragma unroll
-            for (int k = c; k < r; ++k) v -= L[r][k] * M[k][c];
+            for (int k = c + 1; k < r; ++k) v -= L[r][k] * M[k][c];
             M[r][c] = v;
+            m_f2 += v * v;
         }
+    // Certificate: C^-1 = M^T D^-1 M, so |C^-1|_2 <= |M|_F^2 / d_min, and |C|_2 <= |C|_F: when their product is below 5e5
+    // no singular value can fall under the reference's max/1e6 cut-off and the plain inverse is what the reference
+    // computes too.  The bound over-estimates the condition number ~4x on real ICP systems (cond ~1e3, bound ~4e3:
+    // profiles/r01_sweeps.md), so everything up to cond ~1e5 stays on this path.
+    if (!(c_f2 * (m_f2 * m_f2) < (5e5 * 5e5) * (dmin * dmin))) return false;
+    // x = M^T D^-1 M b
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v += M[i][k] * b[k];
+        y[i] = v * invd[i];
     }
-    // C^-1 = M^T D^-1 M (symmetric): entries, Frobenius norm and x = C^-1 b in one sweep
-    double inv_f2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        double v = y[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = j; k < 6; ++k) v += M[k][i] * M[k][j] * invd[k];
-            inv_f2 += (i == j) ? v * v : 2.0 * v * v;
-            x[i] += v * b[j];
-            if (i != j) x[j] += v * b[i];
-        }
-    return c_f2 * inv_f2 < 5e5 * 5e5;
+        for (int k = i + 1; k < 6; ++k) v += M[k][i] * y[k];
+        x[i] = v;
+    }
+    return true;
 }
 
 }  // namespace kf

@@ -528,6 +528,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     HIP_TRY(hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
     c->viewPose = pose;
     kfh_reset(c);
+    launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     if (getenv("KERNEL_TIMINGS")) { c->kernel_timings = true; c->prof_mask = (1u << KFH_PROF_COUNT) - 1u; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return c;
