@@ -81,6 +81,9 @@ struct SideWork {
     unsigned ray_tiles_x, ray_tiles_y;
 };
 
+// OP_TRACK_BEGIN of the next queued frame, carried by a raycast launch (kf_kernels.hip, SkipGrid::next_state)
+struct NextTrackBegin { DevState *state; float k[4]; unsigned frame, tracking_rate; };
+
 namespace launch {
 unsigned track_blocks(unsigned w, unsigned h);
 unsigned bilateral_tiles(unsigned W, unsigned H);
@@ -129,7 +132,7 @@ void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipS
 void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, hipStream_t s);
+             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, const NextTrackBegin *next, hipStream_t s);
 // raycast dispatch order (most expensive screen tiles of the previous launch first): ray_tiles() entries each
 unsigned ray_tiles(unsigned W, unsigned H);
 void init_ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned n, hipStream_t s);

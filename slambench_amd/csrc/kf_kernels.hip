@@ -619,17 +619,19 @@ __global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction
 // Control kernel: the scalar glue of Kfusion::tracking / integration / raycasting (cpp:924-1004) run by one
 // thread on the device, so frame gating and pose algebra need no host round trip.
 // =====================================================================================
+__device__ __forceinline__ void track_begin(DevState *__restrict__ st, bool track_frame, const float k[4]) {
+    for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
+    if (track_frame) {
+        st->oldPose = st->pose;                                  // cpp:947
+        st->track.have_reference = st->have_reference;
+        if (st->have_reference)                                  // cpp:948
+            st->track.view = matmul(camera_matrix(k[0], k[1], k[2], k[3]), inverse(st->raycastPose));
+    }
+}
+
 __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, const ControlArgs &a) {
     const bool track_frame = (a.frame % a.tracking_rate) == 0;   // cpp:927
-    if (ops & OP_TRACK_BEGIN) {
-        for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
-        if (track_frame) {
-            st->oldPose = st->pose;                                  // cpp:947
-            st->track.have_reference = st->have_reference;
-            if (st->have_reference)                                  // cpp:948
-                st->track.view = matmul(camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]), inverse(st->raycastPose));
-        }
-    }
+    if (ops & OP_TRACK_BEGIN) track_begin(st, track_frame, a.k);
     if (ops & OP_TRACK_END) {
         if (track_frame) {                                           // cpp:968-969
             M4 p = st->pose;
@@ -1364,6 +1366,11 @@ struct SkipGrid {
     unsigned long long *trace;    // debugging (KFH_RAY_TRACE): per wave {start, end} of the 100 MHz wall clock, else nullptr
     const unsigned *order;        // launch slot -> screen tile (most expensive tiles of the last frame first), or nullptr
     unsigned *cost;               // per screen tile: march rounds of its longest ray, for the next frame's order
+    // the NEXT queued frame's OP_TRACK_BEGIN (scalar glue, ~3 us as a launch of its own), done by one thread of the last -
+    // cheapest - slot while the rest of the launch marches; nothing in this launch reads what it writes
+    DevState *next_state;         // nullptr = none
+    float next_k[4];
+    unsigned next_frame, next_tracking_rate;
 };
 
 template <class V>
@@ -1584,6 +1591,8 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     // first instead of wherever the raster order puts them - often the last dispatch round (measured: 65 -> see
     // profiles/r01_sweeps.md).  The order only decides WHEN a tile is computed.
     const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x;
+    if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
+        track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
     const unsigned tile = sg.order ? sg.order[slot] : slot;
     unsigned x, y;
     tile_pixel<Q>(x, y, tile % gridDim.x, tile / gridDim.x);
@@ -1949,6 +1958,8 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     g.two_phase = (flags && tp) ? 1 : 0;
     g.trace = nullptr;
     g.order = nullptr; g.cost = nullptr;
+    g.next_state = nullptr; g.next_frame = 0; g.next_tracking_rate = 1;
+    for (int i = 0; i < 4; ++i) g.next_k[i] = 0.f;
     return g;
 }
 
@@ -2035,9 +2046,13 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
 
 void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy,
              unsigned sz, f3 dim, const RayParams *p, float nearPlane, float farPlane, float step, float largestep,
-             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, hipStream_t s) {
+             const unsigned char *skip_flags, unsigned *tile_order, unsigned *tile_cost, const NextTrackBegin *next, hipStream_t s) {
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
     SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
+    if (next && next->state) {
+        sg.next_state = next->state; sg.next_frame = next->frame; sg.next_tracking_rate = next->tracking_rate ? next->tracking_rate : 1;
+        for (int i = 0; i < 4; ++i) sg.next_k[i] = next->k[i];
+    }
     if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
     static WaveTrace wt("KFH_RAY_TRACE");
     const dim3 tg = ray_grid(ray_group(), W, H);

@@ -71,6 +71,8 @@ struct kfh_context {
         float icp_threshold = 0, mu = 0;
         unsigned frame = 0, tracking_rate = 1, integration_rate = 1;
     } pend;
+    bool track_begun = false;          // the device already ran OP_TRACK_BEGIN for frame `track_begun_frame` (inside a raycast launch)
+    unsigned track_begun_frame = 0, track_begun_rate = 1;
     float4 *d_vertex = nullptr, *d_normal = nullptr;
     int *d_result = nullptr;
     float *d_partials = nullptr;      // two buffers of track_blocks_max() x 32, alternating by ICP iteration
@@ -237,6 +239,7 @@ struct NextFrameWork {
     unsigned inW = 0, inH = 0;
     bool pyramid = false;
     float k[4] = {0, 0, 0, 0};
+    unsigned frame = 0, tracking_rate = 1;
 };
 
 static void fill_side_bilateral(const kfh_context *c, const NextFrameWork &nw, SideWork &w, unsigned first, unsigned count) {
@@ -273,8 +276,11 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                              const NextFrameWork *next = nullptr) {
     ControlArgs a;
     fill_control(c, a, k, frame, tracking_rate, integration_rate);
+    // the previous queued frame's raycast launch may have run this frame's OP_TRACK_BEGIN already
+    const bool begun = c->track_begun && c->track_begun_frame == frame && c->track_begun_rate == a.tracking_rate;
+    c->track_begun = false;
     if (frame % a.tracking_rate != 0) {   // cpp:927-928: nothing runs, not even the pyramid
-        launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN | end_ops, a, c->stream);
+        launch::control(c->d_state, c->d_log, (begun ? 0 : OP_TRACK_BEGIN) | end_ops, a, c->stream);
         return false;
     }
     const int L = (int)c->iterations.size();
@@ -307,7 +313,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     const bool placed = next && !bil_its.empty();
     const unsigned bil_tiles = launch::bilateral_tiles(c->W, c->H), pyr_tiles = launch::pyramid_tiles(c->W, c->H);
     prof_begin(c, KFH_PROF_ICP);
-    launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
+    if (!begun) launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
     float *part[2] = {c->d_partials, c->d_partials + (size_t)launch::track_blocks_max() * 32};
     int it = 0, prev_level = 0;
     unsigned prev_nb = 0;
@@ -356,15 +362,22 @@ static void enqueue_integrate(kfh_context *c, float mu) {
     prof_end(c, KFH_PROF_INTEGRATE);
 }
 
-static void enqueue_raycast(kfh_context *c, float mu) {
+static void enqueue_raycast(kfh_context *c, float mu, const NextFrameWork *next = nullptr) {
     if (c->ray_order_stale) {   // no ICP launch took the sort along (untracked frame, phase calls): run it on its own
         launch::ray_order(c->d_ray_order, c->d_ray_cost, c->W, c->H, c->stream);
         c->ray_order_stale = false;
     }
     prof_begin(c, KFH_PROF_RAYCAST);
+    NextTrackBegin nb;
+    std::memset(&nb, 0, sizeof nb);
+    if (next) {   // queued frames: the next frame's tracking preamble rides on this launch
+        nb.state = c->d_state; nb.frame = next->frame; nb.tracking_rate = next->tracking_rate ? next->tracking_rate : 1;
+        for (int i = 0; i < 4; ++i) nb.k[i] = next->k[i];
+        c->track_begun = true; c->track_begun_frame = nb.frame; c->track_begun_rate = nb.tracking_rate;
+    }
     launch::raycast(c->d_vertex, c->d_normal, c->W, c->H, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
                     &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->d_ray_order,
-                    c->d_ray_cost, c->stream);
+                    c->d_ray_cost, next ? &nb : nullptr, c->stream);
     c->ray_order_stale = launch::ray_reorder_enabled();
     prof_end(c, KFH_PROF_RAYCAST);
 }
@@ -385,7 +398,7 @@ static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
         // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the integrate
         // gate (tracking verdict) is the device flag the kernel reads
         if ((p.frame % p.integration_rate) == 0 || p.frame <= 3) enqueue_integrate(c, p.mu);
-        if (p.frame > 2) enqueue_raycast(c, p.mu);
+        if (p.frame > 2) enqueue_raycast(c, p.mu, next);
         c->pend.valid = false;
         c->mirror_stale = true;
     }
@@ -409,6 +422,7 @@ static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
 static inline void flush_frame(kfh_context *c) {
     if (c && c->pend.valid) finish_pending_frame(c, nullptr);
     if (c) c->prof_now = true;   // phase calls and renders are always timed when their phase is enabled
+    if (c) c->track_begun = false;   // whatever follows may change what OP_TRACK_BEGIN reads: it will run again (it is idempotent)
 }
 
 static const uint16_t *stage_input(kfh_context *c, const uint16_t *host, unsigned inW, unsigned inH) {
@@ -673,6 +687,7 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
         if (!nw.d_in) return KFH_ERR_HIP;
         nw.inW = in_width; nw.inH = in_height;
         nw.pyramid = (frame % tracking_rate) == 0;
+        nw.frame = frame; nw.tracking_rate = tracking_rate;
         for (int i = 0; i < 4; ++i) nw.k[i] = k[i];
         finish_pending_frame(c, &nw);    // the previous queued frame's second part, with this frame's first part riding on it
         c->pend.valid = true;
@@ -1048,7 +1063,7 @@ void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const
     RayParams *d = upload_ray(view16, s);
     if (!d) return;
     launch::raycast(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), w, h, vol, size[0], size[1], size[2],
-                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, nullptr, nullptr, nullptr, s);
+                    mk3(dim[0], dim[1], dim[2]), d, near_plane, far_plane, step, largestep, nullptr, nullptr, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 

@@ -127,14 +127,19 @@ np.savez(sys.argv[1], pose=g.get_pose(), vertex=g.buffer("vertex"), normal=g.buf
 
 
 def test_ray_march_variants_agree(hip, tmp_path):
-    """Lanes per ray (1, 2, 4, 8) and empty-space skipping on/off are performance knobs only: every variant must
-    reproduce the same bits (each runs in its own process because the knobs are read once per process)."""
+    """Lanes per ray (1, 2, 4, 8), empty-space skipping, the cost-ordered tile dispatch, the division by reciprocal and
+    the queued-frame pipelining are performance knobs only: every variant must reproduce the same bits (each runs in its
+    own process because the knobs are read once per process)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "variant.py"
     script.write_text(SCRIPT % root)
     outs = []
-    for env in ({"KFH_RAY_GROUP": "1", "KFH_NO_SKIP": "1"}, {"KFH_RAY_GROUP": "4"}, {"KFH_RAY_GROUP": "8"}, {"KFH_RAY_GROUP": "2", "KFH_NO_SKIP": "1"}):
-        out = str(tmp_path / ("v_%s_%s.npz" % (env.get("KFH_RAY_GROUP"), env.get("KFH_NO_SKIP", "0"))))
+    variants = ({"KFH_RAY_GROUP": "1", "KFH_NO_SKIP": "1", "KFH_EXACT_DIV": "0", "KFH_RAY_REORDER": "0", "KFH_PIPELINE": "0"},
+                {"KFH_RAY_GROUP": "4"}, {"KFH_RAY_GROUP": "8"}, {"KFH_RAY_GROUP": "2", "KFH_NO_SKIP": "1"},
+                {"KFH_RAY_GROUP": "4", "KFH_RAY_REORDER": "0"}, {"KFH_RAY_GROUP": "4", "KFH_EXACT_DIV": "0"},
+                {"KFH_RAY_GROUP": "4", "KFH_PIPELINE": "0"}, {"KFH_RAY_GROUP": "1"})
+    for i, env in enumerate(variants):
+        out = str(tmp_path / ("v_%d.npz" % i))
         r = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
