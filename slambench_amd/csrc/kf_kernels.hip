@@ -785,8 +785,12 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     if (staged) for (unsigned i = tid; i < n; i += nthr) sh.cost[i] = cost[i];
     __syncthreads();
     const unsigned *src = staged ? sh.cost : cost;
-    for (unsigned i = tid; i < n; i += nthr) {
-        const int tx = i % tiles_x, ty = i / tiles_x;
+    const float inv_tx = 1.0f / (float)tiles_x;
+    constexpr int KEEP = RAY_ORDER_LDS_TILES / 1024;      // keys of a staged sort stay in registers between the passes
+    unsigned keys[KEEP];
+    int slot = 0;
+    for (unsigned i = tid; i < n; i += nthr, ++slot) {
+        const int ty = (int)(((float)i + 0.5f) * inv_tx), tx = (int)i - ty * (int)tiles_x;   // exact: i < 2^23
         unsigned m = 0;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
@@ -794,7 +798,7 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
                 if (x >= 0 && y >= 0 && x < (int)tiles_x && y < (int)tiles_y) { const unsigned c = src[x + y * tiles_x]; m = m > c ? m : c; }
             }
         const unsigned b = (m >> 2) < RAY_COST_BUCKETS - 1 ? (m >> 2) : RAY_COST_BUCKETS - 1;
-        key[i] = b;
+        if (staged && slot < KEEP) keys[slot] = b; else key[i] = b;
         atomicAdd(&sh.hist[b], 1u);
     }
     __syncthreads();
@@ -809,8 +813,10 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     }
     if (tid < RAY_COST_BUCKETS) sh.offs[RAY_COST_BUCKETS - 1 - tid] = sh.scan[tid] - sh.hist[RAY_COST_BUCKETS - 1 - tid];
     __syncthreads();
-    for (unsigned i = tid; i < n; i += nthr) {
-        order[atomicAdd(&sh.offs[key[i]], 1u)] = i;
+    slot = 0;
+    for (unsigned i = tid; i < n; i += nthr, ++slot) {
+        const unsigned b = (staged && slot < KEEP) ? keys[slot] : key[i];
+        order[atomicAdd(&sh.offs[b], 1u)] = i;
         cost[i] = 0;
     }
 }
@@ -918,8 +924,11 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
     __shared__ IcpShared sh;
     __shared__ float tiles[SIDE_TEAMS][PBY + 2 * PR][PBX + 2 * PR + 1];
     __shared__ double exp_tab[32];
+    __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
-    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks;
+    const unsigned order_blocks = a.ray_order ? 1u : 0u;     // the raycast dispatch sort, if asked for, is the last block
+    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y); return; }
+    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
     const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
     if (threadIdx.x < 32) exp_tab[threadIdx.x] = __builtin_bit_cast(double, kExp2fTable[threadIdx.x]);
     const unsigned tiles_x = (sb.W + PBX - 1) / PBX;
@@ -1899,7 +1908,12 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
         sb.inW = side->inW; sb.ratio = side->ratio; sb.g = side->gauss; sb.e_d_squared_2 = side->e_d * side->e_d * 2;
         sb.first = side->first; sb.count = side->count;
-        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks), ICP_THREADS, 0, s>>>(a, sb);
+        unsigned extra = 0;
+        if (side->ray_order) {   // the raycast dispatch sort shares the launch
+            a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y;
+            extra = 1;
+        }
+        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks + extra) + extra, ICP_THREADS, 0, s>>>(a, sb);
         return;
     }
     if (side && side->kind == SideWork::PYRAMID && side->count) {

@@ -335,12 +335,12 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                     fill_side_pyramid(c, *next, side, lo, hi - lo);
                     sp = &side;
                 }
-            if (!sp && it == 0 && c->ray_order_stale) {   // the raycast dispatch sort rides on the first launch
-                std::memset(&side, 0, sizeof side);
-                side.kind = SideWork::RAY_ORDER;
+            // the raycast dispatch sort (one block, ~9 us alone) shares the first bilateral side launch, which lasts that
+            // long anyway; without one (no next frame queued) it rides on the first launch
+            if (c->ray_order_stale && ((sp && sp->kind == SideWork::BILATERAL) || (!placed && !sp && it == 0))) {
+                if (!sp) { std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side; }
                 side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost;
                 launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
-                sp = &side;
                 c->ray_order_stale = false;
             }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
