@@ -79,6 +79,7 @@ struct SideWork {
     // RAY_ORDER (dispatch order of the next raycast, one block)
     unsigned *ray_order, *ray_cost;
     unsigned ray_tiles_x, ray_tiles_y;
+    unsigned order_mode;              // 0: raycast tiles, 1: integrate blocks (ray_tiles_x = count, ray_tiles_y = 1)
 };
 
 // OP_TRACK_BEGIN of the next queued frame, carried by a raycast launch (kf_kernels.hip, SkipGrid::next_state)
@@ -125,7 +126,12 @@ void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *c
 void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s);
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
-               hipStream_t s);
+               unsigned *block_order, unsigned *block_cost, hipStream_t s);
+// integrate dispatch order (most expensive blocks of the previous launch first): integrate_blocks() entries (order) and
+// twice that (cost + sort keys); init with init_ray_order, sort with integrate_order or as an ICP side block (order_mode 1)
+unsigned integrate_blocks(unsigned sx, unsigned sy, unsigned sz);
+bool integrate_reorder_enabled();
+void integrate_order(unsigned *block_order, unsigned *block_cost, unsigned n, hipStream_t s);
 size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz);
 // verifies once per device and divisor (a few ms, synchronises the stream) the reciprocal form of pos*size/dim of the ray march
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);

@@ -776,8 +776,9 @@ constexpr int RAY_COST_BUCKETS = 256;
 constexpr unsigned RAY_ORDER_LDS_TILES = 8192;     // costs of up to this many tiles are staged in LDS
 struct RayOrderShared { unsigned hist[RAY_COST_BUCKETS], scan[RAY_COST_BUCKETS], offs[RAY_COST_BUCKETS], cost[RAY_ORDER_LDS_TILES]; };
 
+// mode 0: raycast tiles (costs dilated over the 8 neighbours, 4 cost units per bucket); mode 1: integrate blocks (plain).
 __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__restrict__ order, unsigned *__restrict__ cost,
-                                                unsigned tiles_x, unsigned tiles_y) {
+                                                unsigned tiles_x, unsigned tiles_y, unsigned mode) {
     const unsigned n = tiles_x * tiles_y, tid = threadIdx.x, nthr = blockDim.x;
     unsigned *key = cost + n;
     const bool staged = n <= RAY_ORDER_LDS_TILES;
@@ -791,13 +792,16 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     int slot = 0;
     for (unsigned i = tid; i < n; i += nthr, ++slot) {
         const int ty = (int)(((float)i + 0.5f) * inv_tx), tx = (int)i - ty * (int)tiles_x;   // exact: i < 2^23
-        unsigned m = 0;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int x = tx + dx, y = ty + dy;
-                if (x >= 0 && y >= 0 && x < (int)tiles_x && y < (int)tiles_y) { const unsigned c = src[x + y * tiles_x]; m = m > c ? m : c; }
-            }
-        const unsigned b = (m >> 2) < RAY_COST_BUCKETS - 1 ? (m >> 2) : RAY_COST_BUCKETS - 1;
+        unsigned m = src[i];
+        if (mode == 0) {
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = tx + dx, y = ty + dy;
+                    if (x >= 0 && y >= 0 && x < (int)tiles_x && y < (int)tiles_y) { const unsigned c = src[x + y * tiles_x]; m = m > c ? m : c; }
+                }
+            m >>= 2;
+        }
+        const unsigned b = m < RAY_COST_BUCKETS - 1 ? m : RAY_COST_BUCKETS - 1;
         if (staged && slot < KEEP) keys[slot] = b; else key[i] = b;
         atomicAdd(&sh.hist[b], 1u);
     }
@@ -821,9 +825,10 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ray_order(unsigned *__restrict__ order, unsigned *__restrict__ cost, unsigned tiles_x, unsigned tiles_y) {
+__global__ __launch_bounds__(1024) void k_ray_order(unsigned *__restrict__ order, unsigned *__restrict__ cost, unsigned tiles_x, unsigned tiles_y,
+                                                    unsigned mode) {
     __shared__ RayOrderShared sh;
-    ray_order_block(sh, order, cost, tiles_x, tiles_y);
+    ray_order_block(sh, order, cost, tiles_x, tiles_y, mode);
 }
 
 struct IcpIterArgs {
@@ -841,7 +846,7 @@ struct IcpIterArgs {
     float icp_threshold, dist_threshold, normal_threshold;
     unsigned long long *trace;            // debugging (KFH_ICP_TRACE): stamps of block 0 / thread 0, else nullptr
     unsigned *ray_order, *ray_cost;       // side block `nblocks` of a plain launch: raycast dispatch order (nullptr = none)
-    unsigned ray_tiles_x, ray_tiles_y;
+    unsigned ray_tiles_x, ray_tiles_y, order_mode;
 };
 
 __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs &a) {
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_or
     __shared__ IcpShared sh;
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
-    ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y);
+    ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
 }
 
 // ---- side jobs ----------------------------------------------------------------------------------------------------
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // the raycast dispatch sort, if asked for, is the last block
-    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y); return; }
+    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
     const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
     if (threadIdx.x < 32) exp_tab[threadIdx.x] = __builtin_bit_cast(double, kExp2fTable[threadIdx.x]);
@@ -1000,6 +1005,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
 // Every decision and every stored short is the one the CPU loop produces.
 // =====================================================================================
 constexpr short kSkipShortFwd = 26600;
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z);
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1023,11 +1029,19 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
                                                    unsigned zchunk, unsigned long long *__restrict__ updated_total,
                                                    unsigned char *__restrict__ skip_flags, int dbg,
-                                                   unsigned long long *__restrict__ trace) {
+                                                   unsigned long long *__restrict__ trace,
+                                                   const unsigned *__restrict__ order, unsigned *__restrict__ cost) {
     if (!ip->enabled) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
-    const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    unsigned updated = 0;
+    // Launch slot -> block of the (x / 64, y / 4, z-chunk) grid.  As in k_raycast: the launch ends with its slowest
+    // wave (a column chunk lying in the truncation band costs ~10x one outside the frustum), so the blocks that were
+    // expensive in the previous launch are dispatched first instead of wherever x-y-z order puts them (at 512^3 the
+    // far chunks, i.e. the band, used to start 55 us into a 170 us launch).
+    const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned vb = order ? order[slot] : slot;
+    const unsigned vbx = vb % gridDim.x, vby = (vb / gridDim.x) % gridDim.y, vbz = vb / (gridDim.x * gridDim.y);
+    const unsigned x = vbx * 64 + threadIdx.x, y = vby * 4 + threadIdx.y;
+    unsigned updated = 0, work = 0;
     if (x < sx && y < sy) {
         const M4 invTrack = ip->invTrack, K = ip->K;
         const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
@@ -1037,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         ColumnState S;
         S.a = (v2f){pos0.x, pos0.y}; S.b = (v2f){pos0.z, cam0.x}; S.c = (v2f){cam0.y, cam0.z};
         const v2f da = (v2f){delta.x, delta.y}, db = (v2f){delta.z, cameraDelta.x}, dc = (v2f){cameraDelta.y, cameraDelta.z};
-        const unsigned z0 = blockIdx.z * zchunk;
+        const unsigned z0 = vbz * zchunk;
         const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
         for (unsigned z = 0; z < z0; ++z) { S.a += da; S.b += db; S.c += dc; }
         const size_t plane = (size_t)sx * sy;
@@ -1110,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                     T.a += da; T.b += db; T.c += dc;
                 }
             }
+            ++work;
             if (!live || (dbg & 2)) continue;
             float d[IB];
 #pragma unroll
@@ -1128,6 +1143,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                 need |= 1u << i;
             }
             if (!need || (dbg & 4)) continue;
+            work += 4;
             short2 c[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
@@ -1154,10 +1170,14 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             }
         }
     }
-    if (trace && threadIdx.x == 0) {   // debugging (KFH_INTEGRATE_TRACE): per wave {start, end, voxels updated by lane 0, block}
-        const unsigned blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned wave = blk * 4 + threadIdx.y;
-        trace[4 * wave] = t_start; trace[4 * wave + 1] = wall_clock64(); trace[4 * wave + 2] = updated; trace[4 * wave + 3] = blk;
+    if (cost || trace) {   // cost of the block = the busiest lane of its waves: batches examined + 4 x batches updated
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) work = umax_(work, (unsigned)__shfl_xor((int)work, off, 64));
+        if (cost && threadIdx.x == 0 && work) atomicMax(cost + vb, work);
+    }
+    if (trace && threadIdx.x == 0) {   // debugging (KFH_INTEGRATE_TRACE): per wave {start, end, cost, block}
+        const unsigned wave = slot * 4 + threadIdx.y;
+        trace[4 * wave] = t_start; trace[4 * wave + 1] = wall_clock64(); trace[4 * wave + 2] = work; trace[4 * wave + 3] = vb;
     }
     // instrumentation (U = voxels that passed all four tests): one atomic per wave
     if (updated_total) {
@@ -1879,7 +1899,7 @@ static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *par
     a.it = it; a.level = level; a.prev_level = prev_level; a.prev_nblocks = prev_nblocks; a.nblocks = nblocks;
     a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
     a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
-    a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0;
+    a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0; a.order_mode = 0;
     a.trace = nullptr;
     return a;
 }
@@ -1910,7 +1930,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         sb.first = side->first; sb.count = side->count;
         unsigned extra = 0;
         if (side->ray_order) {   // the raycast dispatch sort shares the launch
-            a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y;
+            a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
             extra = 1;
         }
         k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks + extra) + extra, ICP_THREADS, 0, s>>>(a, sb);
@@ -1941,7 +1961,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
     static const int trace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 10; }();
     if (it == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); wt.dump(); return; } }
     if (side && side->kind == SideWork::RAY_ORDER) {
-        a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y;
+        a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
         k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a);
         return;
     }
@@ -2034,27 +2054,43 @@ static long env_long(const char *name, long lo, long hi, long dflt) {
     return (v >= lo && v <= hi) ? v : dflt;
 }
 
-void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
-               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
-               hipStream_t s) {
-    // enough z-chunks to put >= ~8192 waves in flight on 256 CUs; each chunk replays its z0 additions
+// enough z-chunks to put >= ~8192 waves in flight on 256 CUs (each chunk replays its z0 additions, so not more: at
+// 512^3 four chunks of 128 are the measured optimum)
+static dim3 integrate_grid(unsigned sx, unsigned sy, unsigned sz, unsigned *zchunk_out) {
     static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
-    static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
-    static const int dbg = (int)env_long("KFH_INTEGRATE_DBG", 0, 7, 0);
     const unsigned waves_xy = ((sx + 63) / 64) * sy;
     unsigned nchunks = chunks_env ? (unsigned)chunks_env : (8192 + waves_xy - 1) / waves_xy;
+    if (!chunks_env && nchunks < 4 && sz >= 256) nchunks = 4;
     if (nchunks < 1) nchunks = 1;
     if (!chunks_env && nchunks > 16) nchunks = 16;
     if (nchunks > sz) nchunks = sz;
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
-    const dim3 grid((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
+    if (zchunk_out) *zchunk_out = zchunk;
+    return dim3((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
+}
+unsigned integrate_blocks(unsigned sx, unsigned sy, unsigned sz) { const dim3 g = integrate_grid(sx, sy, sz, nullptr); return g.x * g.y * g.z; }
+bool integrate_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_INTEGRATE_REORDER"); return !(e && e[0] == '0'); }(); return on; }
+void integrate_order(unsigned *block_order, unsigned *block_cost, unsigned n, hipStream_t s) {   // sort as a launch of its own
+    k_ray_order<<<1, 1024, 0, s>>>(block_order, block_cost, n, 1u, 1u);
+}
+
+void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
+               const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
+               unsigned *block_order, unsigned *block_cost, hipStream_t s) {
+    static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
+    static const int dbg = (int)env_long("KFH_INTEGRATE_DBG", 0, 7, 0);
+    unsigned zchunk;
+    const dim3 grid = integrate_grid(sx, sy, sz, &zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);
     static WaveTrace wt("KFH_INTEGRATE_TRACE");
     unsigned long long *trace = wt.arm((size_t)grid.x * grid.y * grid.z * 4, s);
-    if (batch_env >= 16) k_integrate<16><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
-    else if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
-    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
-    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace);
+    const bool reorder = integrate_reorder_enabled() && block_order && block_cost;
+    const unsigned *order = reorder ? block_order : nullptr;
+    unsigned *cost = reorder ? block_cost : nullptr;
+    if (batch_env >= 16) k_integrate<16><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
+    else if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
+    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
+    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
     wt.dump();
 }
 
@@ -2092,7 +2128,7 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
 
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
     const dim3 tg = ray_grid(ray_group(), W, H);
-    k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y);
+    k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y, 0u);
 }
 void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_grid(ray_group(), W, H); *tx = g.x; *ty = g.y; }
 bool ray_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_RAY_REORDER"); return !(e && e[0] == '0'); }(); return on; }

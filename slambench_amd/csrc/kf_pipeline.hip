@@ -83,6 +83,9 @@ struct kfh_context {
     bool use_skip = true;
     unsigned *d_ray_order = nullptr, *d_ray_cost = nullptr;   // raycast tile dispatch order / per-tile cost of the last launch
     bool ray_order_stale = false;      // a raycast has left new costs that no sort has consumed yet
+    unsigned *d_int_order = nullptr, *d_int_cost = nullptr;   // the same for the blocks of k_integrate
+    bool int_order_stale = false;
+    unsigned int_blocks = 0;
     DevState *d_state = nullptr;
     FrameLogEntry *d_log = nullptr;
     unsigned log_capacity = 8192;
@@ -339,9 +342,14 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             // long anyway; without one (no next frame queued) it rides on the first launch
             if (c->ray_order_stale && ((sp && sp->kind == SideWork::BILATERAL) || (!placed && !sp && it == 0))) {
                 if (!sp) { std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side; }
-                side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost;
+                side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost; side.order_mode = 0;
                 launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
                 c->ray_order_stale = false;
+            } else if (c->int_order_stale && sp && sp->kind == SideWork::BILATERAL && !side.ray_order) {
+                // ... and the sort of the integrate blocks shares the second one
+                side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
+                side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
+                c->int_order_stale = false;
             }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
@@ -356,9 +364,16 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
 }
 
 static void enqueue_integrate(kfh_context *c, float mu) {
+    if (c->int_order_stale) {   // no ICP launch took the sort along: run it on its own
+        launch::integrate_order(c->d_int_order, c->d_int_cost, c->int_blocks, c->stream);
+        c->int_order_stale = false;
+    }
     prof_begin(c, KFH_PROF_INTEGRATE);
     launch::integrate(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim, c->d_floatDepth, c->W, c->H,
-                      &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->use_skip ? c->d_skip : nullptr, c->stream);
+                      &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->use_skip ? c->d_skip : nullptr,
+                      c->d_int_order, c->d_int_cost, c->stream);
+    // (a launch the device-side gate disables leaves all costs at zero: the sort then keeps the identity order)
+    c->int_order_stale = launch::integrate_reorder_enabled();
     prof_end(c, KFH_PROF_INTEGRATE);
 }
 
@@ -522,6 +537,10 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_ray_order, (size_t)launch::ray_tiles(width, height) * sizeof(unsigned)));
     ok &= HIP_TRY(hipMalloc(&c->d_ray_cost, (size_t)2 * launch::ray_tiles(width, height) * sizeof(unsigned)));   // raw costs + sort keys
     if (ok) launch::init_ray_order(c->d_ray_order, c->d_ray_cost, launch::ray_tiles(width, height), c->stream);
+    c->int_blocks = launch::integrate_blocks(res[0], res[1], res[2]);
+    ok &= HIP_TRY(hipMalloc(&c->d_int_order, (size_t)c->int_blocks * sizeof(unsigned)));
+    ok &= HIP_TRY(hipMalloc(&c->d_int_cost, (size_t)2 * c->int_blocks * sizeof(unsigned)));
+    if (ok) launch::init_ray_order(c->d_int_order, c->d_int_cost, c->int_blocks, c->stream);
     { const char *e = getenv("KFH_NO_SKIP"); c->use_skip = !(e && e[0] == '1'); }
     ok &= HIP_TRY(hipMalloc(&c->d_state, sizeof(DevState)));
     ok &= HIP_TRY(hipMalloc(&c->d_log, (size_t)c->log_capacity * sizeof(FrameLogEntry)));
@@ -592,7 +611,7 @@ void kfh_destroy(kfh_context *c) {
     for (float *p : c->alt_scaled) hipFree(p);
     for (float4 *p : c->alt_inV) hipFree(p);
     for (float4 *p : c->alt_inN) hipFree(p);
-    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip); hipFree(c->d_ray_order); hipFree(c->d_ray_cost);
+    hipFree(c->d_vertex); hipFree(c->d_normal); hipFree(c->d_result); hipFree(c->d_partials); hipFree(c->d_icp); hipFree(c->d_volume); hipFree(c->d_skip); hipFree(c->d_ray_order); hipFree(c->d_ray_cost); hipFree(c->d_int_order); hipFree(c->d_int_cost);
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
     for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
@@ -1041,7 +1060,7 @@ void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], c
     std::memset(&hp, 0, sizeof hp);
     hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
     HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
-    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, s);
+    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 
