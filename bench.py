@@ -172,6 +172,7 @@ def main():
     prof = kf.read_profile()
     updated = kf.integrate_updated()
     icp_iters = kf.icp_iterations()
+    icp_by_level = kf.icp_level_iterations()
     fallbacks = kf.solve_fallbacks()
     poses, tracked, integrated = kf.frame_log(n_frames)
     kf.close()
@@ -207,10 +208,16 @@ def main():
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tpath):
-        for kname, v in json.load(open(tpath)).items():
+        tj = json.load(open(tpath))
+        for kname, v in tj.items():
             for short in ("integrate", "raycast"):
                 if ("k_" + short) in kname:
                     traffic[short] = v["hbm_bytes_per_launch"]
+        # the ICP loop of a frame = all k_icp_iter* launches + k_icp_final (+ k_control when it is a launch of its own)
+        frames_t = sum(v["launches"] for kname, v in tj.items() if "k_icp_final" in kname)
+        loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
+        if frames_t and loop_t:
+            traffic["icp"] = round(loop_t / frames_t)
     P = W * H
     roof = {}
     for name in ("integrate", "raycast"):
@@ -226,7 +233,24 @@ def main():
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n, "sampled_every_n_frames": args.profile_every,
                       "algorithmic_bytes_per_launch": round(alg)}
-    dominant = max(roof, key=lambda k: prof[k][0]) if roof else None
+    # The ICP loop of a frame (19 launches of k_icp_iter*, k_icp_final): 48 bytes per associated pixel (two float4 input
+    # maps, a 32-byte gather from the reference maps) for every EXECUTED iteration, plus - on the queued-frame path - the
+    # next frame's bilateral filter (2P in, 8P out) and pyramid (4P in, 36 bytes per pixel of every level out) that ride
+    # on it.  One "launch" of this entry is one frame's loop.
+    ms, n = prof["icp"]
+    if n:
+        levels = len(pyramid)
+        px = [(W >> l) * (H >> l) for l in range(levels)]
+        alg = 48.0 * sum(icp_by_level[l] * px[l] for l in range(levels)) / max(1, n_frames)
+        alg += 10.0 * P + 4.0 * P + 36.0 * sum(px)
+        avg_s = ms / n * 1e-3
+        gbs = alg / avg_s / 1e9
+        roof["icp"] = {"kernel": "k_icp_iter* + k_icp_final (one frame's ICP loop, %d launches)" % (sum(pyramid) + 1), "bound": "hbm",
+                       "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                       "traffic": traffic.get("icp"), "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                       "sampled_every_n_frames": args.profile_every, "algorithmic_bytes_per_launch": round(alg),
+                       "executed_iterations_per_frame_by_level": [round(v / max(1, n_frames), 2) for v in icp_by_level]}
+    dominant = max(roof, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if roof else None
     if spg > 1:
         args.steps_label = "%d frames x %d streams" % (args.steps, spg)
     out = {

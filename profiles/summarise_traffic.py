@@ -40,6 +40,9 @@ def main(out):
             "fetch_kib_raw": round(f_kib, 1), "write_kib": round(w_kib, 1),
             "hbm_bytes_per_launch_raw": round((f_kib + w_kib) * 1024),
             "hbm_bytes_per_launch": round((2 * f_kib + w_kib) * 1024),
+            # over ALL launches of the run (the ICP loop is many launches of several kernels: bench.py adds these up
+            # and divides by the frames of the run, i.e. the launches of k_icp_final)
+            "hbm_bytes_total": round((2 * sum(f) + sum(w)) * 1024),
         }
     json.dump(res, open(out + "/traffic.json", "w"), indent=1)
     for k, v in res.items():

@@ -29,6 +29,7 @@ struct DevState {
     unsigned long long icp_iterations;
     unsigned long long integrate_updated;   // U of SURVEY §8(d), summed over all integrate launches
     unsigned long long solve_fallbacks;     // ICP solves that needed the Jacobi path (ill-conditioned J^T J)
+    unsigned long long icp_level_iterations[KFH_MAX_LEVELS];   // icp_iterations by pyramid level
 };
 
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran

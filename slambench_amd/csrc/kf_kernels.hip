@@ -758,6 +758,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
         if (converged) sh.done[prev_level] = 1;
         if (writer) {
             st->icp_iterations += 1;
+            st->icp_level_iterations[prev_level] += 1;
             if (!fast) st->solve_fallbacks += 1;
         }
     }

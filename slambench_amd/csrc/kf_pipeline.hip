@@ -845,6 +845,11 @@ int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t lau
 }
 
 uint64_t kfh_icp_iterations(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->icp_iterations; }
+void kfh_icp_level_iterations(kfh_context *c, uint64_t out[KFH_MAX_LEVELS]) {
+    c->mirror_stale = true;
+    refresh_mirror(c);
+    for (int l = 0; l < KFH_MAX_LEVELS; ++l) out[l] = c->h_state->icp_level_iterations[l];
+}
 
 // ------------------------------------------------------------------ buffer access for parity checks
 static bool find_buffer(kfh_context *c, const std::string &n, void **ptr, size_t *bytes) {

@@ -153,6 +153,12 @@ class Kfusion:
     def icp_iterations(self):
         return int(self.L.kfh_icp_iterations(self.h))
 
+    def icp_level_iterations(self):
+        """executed ICP iterations by pyramid level (index 0 = full resolution)"""
+        out = (C.c_uint64 * 8)()   # KFH_MAX_LEVELS
+        self.L.kfh_icp_level_iterations(self.h, out)
+        return [int(v) for v in out][:len(self.pyramid)]
+
     def solve_fallbacks(self):
         return int(self.L.kfh_solve_fallbacks(self.h))
 
