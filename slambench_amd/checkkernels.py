@@ -11,6 +11,7 @@ import sys
 
 KERNEL_CONSISTENCY = [
     ["mm2meters", "mm2metersKernel"],
+    ["pyramid", "pyramidKernel"],     # HIP only: half-sampling + vertex/normal maps of all levels in one launch
     ["bilateral_filter", "bilateralFilterKernel"],
     ["halfSampleRobust", "halfSampleRobustImageKernel"],
     ["depth2vertex", "depth2vertexKernel"],
@@ -51,7 +52,7 @@ def main(argv=None) -> int:
         print("I need only one parameter, the kernel log file.")
         return 1
     print("\nKernel-level statistics. Times are in nanoseconds.")
-    rep = summarise(open(argv[1]).read())
+    rep = summarise(sys.stdin.read() if argv[1] == "-" else open(argv[1]).read())
     for name in sorted(rep):
         s = rep[name]
         print("%20.20s\tCount : %d\tMin   : %d\tMax   : %d\tMean  : %f\tTotal : %d" % (name, s["count"], s["min"], s["max"], s["mean"], s["total"]))

@@ -4,7 +4,7 @@ import subprocess
 
 import numpy as np
 
-from slambench_amd import checkpos, rawio, synth
+from slambench_amd import checkkernels, checkpos, perfstats, rawio, rocprof2log, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -83,3 +83,36 @@ def test_benchmark_cli_rejects_bad_flags():
     assert r.returncode == 0 and "Unknown option" in r.stderr       # the reference exits 0 here
     r = run()
     assert r.returncode == 1 and "No input found." in r.stderr
+
+
+def test_perfstats_summary_block():
+    """PerfStats::print_all_data's closing block (perfstats.h:330-343): mean, POPULATION standard deviation, min, max."""
+    pos = np.zeros((4, 3))
+    text = _fake_log(pos, [1, 1, 1, 1]).split("\n")
+    rows = [r.split("\t") for r in text[1:5]]
+    for i, r in enumerate(rows):
+        r[7] = "%.6f" % (0.001 * (i + 1))            # computation column: 1, 2, 3, 4 ms
+    text = "\n".join([text[0]] + ["\t".join(r) for r in rows]) + "\n"
+    st = perfstats.summary(text)
+    assert "frame" not in st and st["computation"]["n"] == 4
+    assert abs(st["computation"]["mean"] - 0.0025) < 1e-12 and abs(st["computation"]["sd"] - np.std([1e-3, 2e-3, 3e-3, 4e-3])) < 1e-12
+    assert st["computation"]["min"] == 0.001 and st["computation"]["max"] == 0.004
+    out = perfstats.render(st)
+    assert out.count("\n") == 13 and "#   computation\tMean:\t0.0025000000\tStandard deviation:\t" in out
+
+
+def test_rocprof_trace_to_kernel_log():
+    """rocprofv3 kernel-trace rows come out as `<reference kernel name> <ns>` lines that checkkernels aggregates (the
+    nvprof2log.py -> checkKernels.py chain of the reference)."""
+    rows = [
+        {"Kernel_Name": "void kf::k_raycast<4, 1>(HIP_vector_type<float, 4u>*, ...)", "Start_Timestamp": "3000", "End_Timestamp": "53000"},
+        {"Kernel_Name": "kf::k_icp_iter(kf::IcpIterArgs)", "Start_Timestamp": "1000", "End_Timestamp": "2500"},
+        {"Kernel_Name": "kf::k_icp_iter_bilateral(kf::IcpIterArgs, kf::SideBilateral)", "Start_Timestamp": "2500", "End_Timestamp": "3000"},
+        {"Kernel_Name": "void kf::k_integrate<8>(HIP_vector_type<short, 2u>*, ...)", "Start_Timestamp": "500", "End_Timestamp": "900"},
+        {"Kernel_Name": "__amd_rocclr_fillBufferAligned", "Start_Timestamp": "0", "End_Timestamp": "100"},
+        {"Kernel_Name": "void kf::k_bilateral<true>(float*, float*, ...)", "Start_Timestamp": "100", "End_Timestamp": "400"},
+    ]
+    lines = rocprof2log.convert(rows)
+    assert lines == [("bilateralFilterKernel", 300), ("integrateKernel", 400), ("trackKernel", 1500), ("trackKernel", 500), ("raycastKernel", 50000)]
+    rep = checkkernels.summarise("\n".join("%s %d" % l for l in lines))
+    assert rep["track"]["count"] == 2 and rep["track"]["total"] == 2000 and rep["raycast"]["mean"] == 50000 and rep["bilateral_filter"]["count"] == 1
