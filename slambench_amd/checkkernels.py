@@ -11,7 +11,6 @@ import sys
 
 KERNEL_CONSISTENCY = [
     ["mm2meters", "mm2metersKernel"],
-    ["pyramid", "pyramidKernel"],     # HIP only: half-sampling + vertex/normal maps of all levels in one launch
     ["bilateral_filter", "bilateralFilterKernel"],
     ["halfSampleRobust", "halfSampleRobustImageKernel"],
     ["depth2vertex", "depth2vertexKernel"],
