@@ -164,3 +164,31 @@ def test_four_level_pyramid(hip, kfmod, orc):
         g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
     assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
     g.close(); o.close()
+
+
+def test_pipeline_1280x960_512_four_levels_against_oracle(hip, kfmod, orc):
+    """BASELINE configs[3] at full size: 1280x960 depth, 512^3 volume, -y 10,5,4,4 (4.7 pixels per ICP thread at level 0,
+    four z-chunks of 128 in integrate, 19 200 raycast tiles - the dispatch sort runs from global memory there).  Three
+    frames of the queued path against the OpenMP oracle: the input maps of all four levels and the TSDF bit-identical
+    (frames 0-2 do not depend on the ICP sums), then the phase path and the queued path against each other."""
+    W4, H4, n = 1280, 960, 3
+    s = util.synth.make_stream(n, W4, H4)
+    k = list(s.k)
+    res, pyr = (512, 512, 512), (10, 5, 4, 4)
+    g = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)
+    q = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)
+    o = orc.OracleKfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr, omp=True)
+    for f in range(n):
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        q.compute_frame(s.depth_mm[f], (W4, H4), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
+    for l in range(4):
+        assert same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l))
+    assert np.array_equal(g.buffer("volume"), o.buffer("volume"))
+    assert same_bits(g.get_pose(), o.get_pose())                       # no reference frame yet: the pose has not moved
+    q.synchronise()
+    for name in ("volume", "vertex", "normal", "trackResult", "inputNormal0", "inputNormal3", "floatDepth"):
+        assert np.array_equal(g.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
+    g.close(); q.close(); o.close()
