@@ -1095,7 +1095,6 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             ColumnState T = first;
             unsigned live = 0;            // bit i: voxel zb+i projects into the image
             unsigned pix[IB];
-            float px_[IB], py_[IB], pz_[IB], camz[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 if ((unsigned)i < nb) {
@@ -1118,7 +1117,6 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                             if (!(px < 0 || px > wm1 || py < 0 || py > hm1)) {     // cpp:651-653
                                 live |= 1u << i;
                                 pix[i] = (unsigned)px + (unsigned)py * W;
-                                px_[i] = T.a.x; py_[i] = T.a.y; pz_[i] = posz; camz[i] = cz;
                             }
                         }
                     }
@@ -1134,11 +1132,12 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
             unsigned need = 0;
             float t_[IB];
+            v2f camc = first.c;               // (cam.y, cam.z), replayed like the positions below
 #pragma unroll
-            for (int i = 0; i < IB; ++i) {
+            for (int i = 0; i < IB; ++i, camc += dc) {
                 if (!(live & (1u << i))) continue;
                 if (d[i] == 0) continue;                                           // cpp:655
-                const float t = d[i] - camz[i];
+                const float t = d[i] - camc.y;
                 if (t <= -mu) continue;
                 t_[i] = t;
                 need |= 1u << i;
@@ -1149,14 +1148,18 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
+            // the world position of a band voxel is replayed from the batch's first state (3 packed adds per voxel) instead
+            // of being kept in 24 registers across the two memory round trips above
+            ColumnState R = first;
 #pragma unroll
-            for (int i = 0; i < IB; ++i) {
+            for (int i = 0; i < IB; ++i, R.a += da, R.b += db, R.c += dc) {
                 if (!(need & (1u << i))) continue;
                 float sdf;
                 if (t_[i] >= mu) {
                     sdf = 1.f;
                 } else {
-                    const float diff = t_[i] * sqrtf(1 + sq(px_[i] / pz_[i]) + sq(py_[i] / pz_[i]));
+                    const float rx = R.a.x, ry = R.a.y, rz = R.b.x;
+                    const float diff = t_[i] * sqrtf(1 + sq(rx / rz) + sq(ry / rz));
                     if (!(diff > -mu)) continue;
                     sdf = fmin_h(1.f, diff / mu);
                 }
