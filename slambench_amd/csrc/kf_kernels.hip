@@ -709,15 +709,10 @@ struct IcpShared {
 
 // Brings `sh` to the state entering iteration `it`: pose and flags after the update of iteration it-1.
 #define ICP_STAMP(i) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[i] = __builtin_readcyclecounter(); } while (0)
-struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
-
-// `after_handover` runs once the state of the previous launch is in LDS (sh.done is valid) and before the sums and the
-// solve: the place to start loads whose latency the prologue can hide.
-template <class F = NoPrefetch>
 __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *__restrict__ iters,
                                             const float *__restrict__ partials_prev, int it, int prev_level,
                                             unsigned prev_nblocks, float icp_threshold, bool writer,
-                                            unsigned long long *trace = nullptr, F after_handover = F()) {
+                                            unsigned long long *trace = nullptr) {
     ICP_STAMP(0);
     if (threadIdx.x == 0) {
         if (it == 0) {
@@ -733,7 +728,6 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     }
     __syncthreads();
     ICP_STAMP(1);
-    after_handover();
     if (!sh.prev_executed) return;   // uniform: the previous iteration was skipped, nothing to solve
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     constexpr int G = ICP_THREADS / 32;
