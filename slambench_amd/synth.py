@@ -159,7 +159,10 @@ def cached_stream(n_frames: int, width: int = 640, height: int = 480, seed: int 
             z = np.load(path)
             return Stream(width, height, camera_for(width), z["depth"], z["poses"], z["poses"][0, :3, 3].copy())
         except Exception:
-            os.remove(path)
+            try:
+                os.remove(path)          # unreadable cache entry; another rank may have removed it already
+            except OSError:
+                pass
     s = make_stream(n_frames, width, height, seed, variant)
     tmp = path + ".tmp%d.npz" % os.getpid()
     np.savez(tmp, depth=s.depth_mm, poses=s.poses)
