@@ -820,36 +820,38 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
         atomicAdd(&sh.hist[r][b], 1u);
     }
     __syncthreads();
-    // per region: offs[b] = number of its tiles in buckets above b (inclusive scan of the reversed histogram minus the own
-    // count).  2048 entries, 1024 threads (the block size of every caller): entries tid and tid + 1024.
-    unsigned *hist = &sh.hist[0][0], *scan = &sh.scan[0][0], *offs = &sh.offs[0][0];
-    constexpr unsigned E = RAY_REGIONS * RAY_COST_BUCKETS;          // 512 entries: one per thread of the first 8 waves
-    static_assert(E <= 1024, "one scan entry per thread");
-    const unsigned j0 = tid % RAY_COST_BUCKETS;
-    const unsigned rev0 = (tid - j0) + (RAY_COST_BUCKETS - 1 - j0);
-    if (tid < E) scan[tid] = hist[rev0];
-    __syncthreads();
-    for (unsigned d = 1; d < RAY_COST_BUCKETS; d <<= 1) {
-        unsigned a0 = 0;
-        if (tid < E) a0 = j0 >= d ? scan[tid - d] : 0u;
-        __syncthreads();
-        if (tid < E) scan[tid] += a0;
-        __syncthreads();
+    // per class: offs[b] = number of its tiles in buckets above b.  One wave per class, one lane per bucket: an inclusive
+    // scan of the reversed histogram by six shuffle steps (no barrier), minus the own count.
+    static_assert(RAY_COST_BUCKETS == 64, "one lane per cost class");
+    if (tid < RAY_REGIONS * 64) {
+        const unsigned r = tid >> 6, lane = tid & 63u, b = RAY_COST_BUCKETS - 1 - lane;
+        const unsigned own = sh.hist[r][b];
+        unsigned v = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)v, d, 64);
+            v += lane >= (unsigned)d ? up : 0u;
+        }
+        sh.offs[r][b] = v - own;
+        if (lane == 63) sh.count[r] = v;                       // tiles of the class
     }
-    if (tid < E) offs[rev0] = scan[tid] - hist[rev0];
-    if (tid < RAY_REGIONS) sh.count[tid] = sh.scan[tid][RAY_COST_BUCKETS - 1];      // tiles of the class = total of its histogram
     __syncthreads();
+    unsigned cmin = sh.count[0];
+    for (unsigned q = 1; q < R; ++q) cmin = cmin < sh.count[q] ? cmin : sh.count[q];
     slot = 0;
     for (unsigned i = tid; i < n; i += nthr, ++slot) {
         const unsigned k = (staged && slot < KEEP) ? keys[slot] : key[i];
         const unsigned r = k >> 8;
         const unsigned pos = atomicAdd(&sh.offs[r][k & 255u], 1u);       // rank of the tile inside its class
         // slot of (class r, rank pos) when the classes take turns and a class that has run out is passed over
-        unsigned s_ = 0;
-        for (unsigned q = 0; q < R; ++q) {
-            const unsigned cq = sh.count[q];
-            s_ += cq < pos ? cq : pos;
-            s_ += (q < r && cq > pos) ? 1u : 0u;
+        unsigned s_ = R * pos + r;                                       // while every class still has tiles
+        if (pos >= cmin) {
+            s_ = 0;
+            for (unsigned q = 0; q < R; ++q) {
+                const unsigned cq = sh.count[q];
+                s_ += cq < pos ? cq : pos;
+                s_ += (q < r && cq > pos) ? 1u : 0u;
+            }
         }
         order[R == 1 ? pos : s_] = i;
         cost[i] = 0;
