@@ -987,8 +987,11 @@ template <int NLEV>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
     __shared__ IcpShared sh;
     __shared__ float lds[SIDE_TEAMS][pyr_lds_floats<NLEV>()];
+    __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
-    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks;
+    const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
+    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
+    const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
     const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
     const unsigned rounds = (sp.count + nside * SIDE_TEAMS - 1) / (nside * SIDE_TEAMS);
@@ -1984,7 +1987,12 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         }
         sp.a.W = side->W; sp.a.H = side->H; sp.a.e_d = side->e_d;
         sp.first = side->first; sp.count = side->count;
-        const unsigned grid = nblocks + side_blocks(side->count, nblocks);
+        unsigned extra = 0;
+        if (side->ray_order) {   // a dispatch sort shares the launch
+            a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
+            extra = 1;
+        }
+        const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
         switch (side->n_levels) {
         case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
         case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;

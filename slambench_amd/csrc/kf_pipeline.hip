@@ -338,15 +338,18 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                     fill_side_pyramid(c, *next, side, lo, hi - lo);
                     sp = &side;
                 }
-            // the raycast dispatch sort (one block, ~9 us alone) shares the first bilateral side launch, which lasts that
-            // long anyway; without one (no next frame queued) it rides on the first launch
-            if (c->ray_order_stale && ((sp && sp->kind == SideWork::BILATERAL) || (!placed && !sp && it == 0))) {
+            // The two dispatch sorts (one block each; raycast tiles ~10 us, integrate blocks ~5.5 us) ride on side launches
+            // that last that long anyway: the raycast sort on the pyramid launch (a pyramid tile alone takes ~10 us), the
+            // integrate sort on the first bilateral one; without such launches (no next frame queued) the raycast sort
+            // rides on the first launch and the integrate sort runs alone just before k_integrate.
+            const bool pyramid_later = placed && !pyr_its.empty() && it < pyr_its.front();
+            if (c->ray_order_stale && ((sp && sp->kind == SideWork::PYRAMID) || (sp && sp->kind == SideWork::BILATERAL && !pyramid_later && pyr_its.empty()) ||
+                                       (!placed && !sp && it == 0))) {
                 if (!sp) { std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side; }
                 side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost; side.order_mode = 0;
                 launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
                 c->ray_order_stale = false;
             } else if (c->int_order_stale && sp && sp->kind == SideWork::BILATERAL && !side.ray_order) {
-                // ... and the sort of the integrate blocks shares the second one
                 side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
                 side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
                 c->int_order_stale = false;
