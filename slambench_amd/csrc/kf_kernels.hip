@@ -1656,8 +1656,9 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     const unsigned long long t_start = sg.trace ? wall_clock64() : 0ull;
     // Launch slot -> screen tile.  Workgroups are dispatched in slot order and the launch ends with its slowest wave, so
     // the tiles whose rays marched longest in the previous frame (grazing views along a surface: up to 4x the mean) go
-    // first instead of wherever the raster order puts them - often the last dispatch round (measured: 65 -> see
-    // profiles/r01_sweeps.md).  The order only decides WHEN a tile is computed.
+    // first instead of wherever the raster order puts them - often the last dispatch round (measured: 65 -> 50 us,
+    // profiles/r01_sweeps.md).  The order also keeps the tiles of a 64x64-pixel super-tile on one XCD (ray_order_block).
+    // It only decides WHEN and WHERE a tile is computed, never what.
     const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x;
     if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
         track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
