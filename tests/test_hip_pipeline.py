@@ -88,6 +88,63 @@ def test_free_running_parity(hip, kfmod, orc, ratio, res, pyramid):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("width,height,pyramid", [(100, 75, (5, 4, 3)), (90, 70, (4, 3)), (36, 28, (6, 4))])
+def test_odd_image_sizes(hip, kfmod, orc, width, height, pyramid):
+    """Sizes the 32x32 pyramid tiles and the 2^(L-1) divisibility of the fused kernels do not cover (the reference's level
+    sizes are integer divisions, cpp:933-934): the per-level kernels run instead and the queued path falls back to plain
+    launches.  Every input map bit-identical to the oracle, poses within tolerance, queued path equal to the phases."""
+    s = util.small_stream(N_FRAMES, width, height)
+    k = list(s.k)
+    res = (40, 40, 40)
+    g = kfmod.Kfusion((width, height), res, util.VOL_DIM, s.init_pos, pyramid)
+    q = kfmod.Kfusion((width, height), res, util.VOL_DIM, s.init_pos, pyramid)
+    o = orc.OracleKfusion((width, height), res, util.VOL_DIM, s.init_pos, pyramid)
+    for f in range(N_FRAMES):
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        for l in range(len(pyramid)):
+            assert same_bits(g.buffer("scaledDepth%d" % l), o.buffer("scaledDepth%d" % l)), (f, l)
+            assert same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l)), (f, l)
+        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        q.compute_frame(s.depth_mm[f], (width, height), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
+    assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
+    q.synchronise()
+    for name in ("volume", "vertex", "normal", "pose", "trackResult"):
+        assert np.array_equal(g.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
+    g.close(); q.close(); o.close()
+
+
+def test_sensor_dropout_and_saturated_frames(hip, kfmod, orc):
+    """A frame of zeros (sensor dropout: every pixel invalid, nothing to associate, nothing integrated), a frame beyond the far
+    plane and a half-empty frame in the middle of a sequence: verdicts, poses and the TSDF follow the oracle, and the
+    queued path follows the phases bit for bit."""
+    s = util.small_stream(N_FRAMES)
+    depth = s.depth_mm.copy()
+    depth[5] = 0
+    depth[7] = 60000                      # 60 m: outside the volume and the far plane
+    depth[8][:, : s.width // 2] = 0
+    k = list(s.k)
+    res = (48, 48, 48)
+    g, q = _make(kfmod, s, res), _make(kfmod, s, res)
+    o = orc.OracleKfusion((s.width, s.height), res, util.VOL_DIM, s.init_pos)
+    for f in range(N_FRAMES):
+        g.preprocessing(depth[f]); o.preprocessing(depth[f])
+        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f), f
+        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f), f
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4, f
+        q.compute_frame(depth[f], (s.width, s.height), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
+    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 2e-3
+    q.synchronise()
+    pa, ta, ia = g.frame_log(N_FRAMES)
+    pq, tq, iq = q.frame_log(N_FRAMES)
+    assert same_bits(pa, pq) and list(ta) == list(tq) and list(ia) == list(iq)
+    assert list(ta)[5] == 0 and list(ta)[7] == 0                       # nothing to track on the empty frames
+    assert np.array_equal(g.buffer("volume"), q.buffer("volume"))
+    g.close(); q.close(); o.close()
+
+
 def test_compute_frame_equals_phases(hip, kfmod):
     """Kfusion::computeFrame queued without host round trips gives the same bits as the four phase calls."""
     s = util.small_stream(N_FRAMES)
