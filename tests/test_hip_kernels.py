@@ -295,6 +295,35 @@ def test_raycast(hip, dev, orc, scene):
         assert same_bits(dev.get(dn)[..., :3], n_ref)
 
 
+@pytest.mark.parametrize("res,dim", [((64, 48, 80), (4.8, 3.6, 6.0)), ((40, 72, 56), (5.0, 4.8, 5.5)), ((96, 96, 32), (4.8, 4.8, 7.0))])
+def test_integrate_and_raycast_anisotropic_volume(hip, dev, orc, scene, res, dim):
+    """Non-cubic resolutions and per-axis extents (Volume carries a uint3 and a float3, commons.h:149-160): the voxel size
+    differs per axis, the ray march divides by three different extents (each divisor of the reciprocal form is verified
+    on the device on first use, otherwise the IEEE division is kept) and the step is min(extent) / max(resolution)."""
+    s = scene["stream"]
+    K = orc.camera_matrix(s.k)
+    vol = orc.init_volume(res)
+    d_vol = dev.put(vol.copy())
+    W, H = s.width, s.height
+    for f in range(3):
+        depth = orc.mm2meters(s.depth_mm[f], W, H)
+        inv_track = orc.inverse(s.poses[f].astype(np.float32))
+        orc.integrate(vol, dim, depth, inv_track, K)
+        hip.kfh_k_integrate(d_vol.data_ptr(), u32(res), f32(dim), dev.put(depth).data_ptr(), W, H, m16(inv_track), m16(K), 0.1, 100.0,
+                            dev.stream)
+    assert np.array_equal(dev.get(d_vol), vol)
+    assert (vol[..., 1] > 0).mean() > 0.01
+    view = orc.matmul(s.poses[2].astype(np.float32), orc.inverse_camera_matrix(s.k))
+    step = float(np.float32(min(dim)) / np.float32(max(res)))
+    v_ref, n_ref = orc.raycast(vol, dim, view, W, H, step=step)
+    dv, dn = dev.empty((H, W, 4), np.float32), dev.empty((H, W, 4), np.float32)
+    hip.kfh_k_raycast(dv.data_ptr(), dn.data_ptr(), W, H, d_vol.data_ptr(), u32(res), f32(dim), m16(view), 0.4, 4.0, step, 0.075,
+                      dev.stream)
+    assert (n_ref[..., 0] != -2).mean() > 0.3
+    assert same_bits(dev.get(dv)[..., :3], v_ref)
+    assert same_bits(dev.get(dn)[..., :3], n_ref)
+
+
 def test_raycast_empty_volume_all_miss(hip, dev, orc):
     res = (32, 32, 32)
     vol = orc.init_volume(res)
