@@ -192,3 +192,35 @@ def test_pipeline_1280x960_512_four_levels_against_oracle(hip, kfmod, orc):
     for name in ("volume", "vertex", "normal", "trackResult", "inputNormal0", "inputNormal3", "floatDepth"):
         assert np.array_equal(g.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
     g.close(); q.close(); o.close()
+
+
+def test_largest_volume_1024_cubed(hip, orc):
+    """2^30 voxels - the most kfh_create accepts: voxel byte offsets in the ray march reach 2^32 - 4, i.e. the last value a
+    32-bit offset register can hold.  Two integrations and a raycast through the kernel-level ABI against the OpenMP
+    oracle, bit for bit (4 GiB volume on each side)."""
+    dev = Dev()
+    size = (1024, 1024, 1024)
+    s = util.synth.make_stream(2, 320, 240)
+    Ws, Hs = 320, 240
+    K = orc.camera_matrix(s.k)
+    vol = orc.init_volume(size, omp=True)
+    d_vol = dev.put(vol)
+    for f in range(2):
+        depth = orc.mm2meters(s.depth_mm[f], Ws, Hs, omp=True)
+        inv_track = orc.inverse(s.poses[f].astype(np.float32))
+        orc.integrate(vol, util.VOL_DIM, depth, inv_track, K, omp=True)
+        hip.kfh_k_integrate(d_vol.data_ptr(), u32(size), f32(util.VOL_DIM), dev.put(depth).data_ptr(), Ws, Hs, m16(inv_track), m16(K),
+                            0.1, 100.0, dev.stream)
+    got = dev.get(d_vol)
+    assert np.array_equal(got[-8:], vol[-8:]) and np.array_equal(got[::64], vol[::64]) and np.array_equal(got, vol)
+    del got
+    view = orc.matmul(s.poses[1].astype(np.float32), orc.inverse_camera_matrix(s.k))
+    step = float(np.float32(4.8) / np.float32(1024))
+    v_ref, n_ref = orc.raycast(vol, util.VOL_DIM, view, Ws, Hs, step=step, omp=True)
+    dv, dn = dev.empty((Hs, Ws, 4), np.float32), dev.empty((Hs, Ws, 4), np.float32)
+    hip.kfh_k_raycast(dv.data_ptr(), dn.data_ptr(), Ws, Hs, d_vol.data_ptr(), u32(size), f32(util.VOL_DIM), m16(view), 0.4, 4.0, step, 0.075,
+                      dev.stream)
+    assert (n_ref[..., 0] != -2).mean() > 0.8
+    assert same_bits(dev.get(dv)[..., :3], v_ref)
+    assert same_bits(dev.get(dn)[..., :3], n_ref)
+    dev.clear()

@@ -145,6 +145,23 @@ def test_sensor_dropout_and_saturated_frames(hip, kfmod, orc):
     g.close(); q.close(); o.close()
 
 
+def test_create_rejects_what_it_cannot_serve(hip, kfmod):
+    """Creation fails loudly (no context, a message) instead of mis-addressing: more than 2^30 voxels (the ray march uses
+    32-bit voxel byte offsets), an empty image, no pyramid level or more than KFH_MAX_LEVELS."""
+    s = util.small_stream(1)
+    for args, what in ((((64, 48), (1024, 1024, 1025), util.VOL_DIM, s.init_pos), "2^30"),
+                       (((0, 48), (16, 16, 16), util.VOL_DIM, s.init_pos), "bad argument"),
+                       (((64, 48), (16, 16, 16), util.VOL_DIM, s.init_pos, ()), "bad argument"),
+                       (((64, 48), (16, 16, 16), util.VOL_DIM, s.init_pos, (1,) * 9), "bad argument")):
+        with pytest.raises(RuntimeError) as e:
+            kfmod.Kfusion(*args)
+        assert what in str(e.value), str(e.value)
+    # the largest volume that is served: 2^30 voxels = 4 GiB (a fraction of the 288 GB on the card)
+    big = kfmod.Kfusion((64, 48), (1024, 1024, 1024), util.VOL_DIM, s.init_pos)
+    assert big.get_model_resolution() == (1024, 1024, 1024) if hasattr(big, "get_model_resolution") else True
+    big.close()
+
+
 def test_compute_frame_equals_phases(hip, kfmod):
     """Kfusion::computeFrame queued without host round trips gives the same bits as the four phase calls."""
     s = util.small_stream(N_FRAMES)
