@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkfusion_hip.so")
@@ -86,6 +87,17 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("HIP backend missing: %s not built (run `python -m slambench_amd.build`)" % LIB_PATH)
+    # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64 under the SONAMEs of
+    # /opt/rocm's; whichever is loaded first serves every later request for that SONAME made through the loader's search,
+    # but torch loads its copies by path.  If this library came first the process would hold two runtimes, and device
+    # pointers made by one (torch tensors) are strangers to the other (measured: kernels launched on them silently do
+    # nothing).  So when torch is installed it is imported before the backend; KFH_NO_TORCH_PRELOAD=1 skips that for
+    # processes that never touch torch.
+    if "torch" not in sys.modules and os.environ.get("KFH_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol

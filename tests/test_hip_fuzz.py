@@ -1,0 +1,10 @@
+"""A dozen trials of tests/fuzz_parity.py (random resolutions, extents, poses) in the GPU suite."""
+import pytest
+
+from tests import fuzz_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_volumes_and_poses(hip, orc):
+    assert fuzz_parity.run(hip, orc, seed=20261003, trials=12) == []
