@@ -58,6 +58,44 @@ def run(hip, orc, seed=7, trials=12, verbose=False):
     return bad
 
 
+def run_maps(kfusion, orc, seed=11, trials=8, verbose=False):
+    """Random depth images with holes (single zero pixels, zero blocks, depth steps) through preprocessing and the input
+    pyramid of the pipeline: filtered depth, half-sampled depths, vertex maps and the validity of the normals, bit for bit."""
+    rng = np.random.default_rng(seed)
+    bad = []
+    for trial in range(trials):
+        W, H = [(160, 120), (100, 76), (64, 48), (320, 240)][trial % 4]
+        pyr = [(4, 3, 2), (3, 2), (2,), (3, 2, 2, 1)][trial % 4]
+        ratio = int(rng.choice([1, 2]))
+        d = rng.uniform(500, 3500, size=(H * ratio, W * ratio))
+        d += 400.0 * (rng.random((H * ratio, W * ratio)) < 0.3) * rng.standard_normal((H * ratio, W * ratio))   # depth steps
+        d[rng.random(d.shape) < 0.1] = 0
+        for _ in range(6):
+            y, x = int(rng.integers(0, H * ratio - 8)), int(rng.integers(0, W * ratio - 8))
+            d[y:y + int(rng.integers(2, 8)), x:x + int(rng.integers(2, 8))] = 0
+        d = np.clip(d, 0, 65535).astype(np.uint16)
+        k = [481.2 * W / 640, 480.0 * H / 480, W / 2.0, H / 2.0]
+        init = np.array([0.34 * 4.8, 0.5 * 4.8, 0.24 * 4.8], np.float32)
+        g = kfusion.Kfusion((W, H), (32, 32, 32), (4.8,) * 3, init, pyr)
+        o = orc.OracleKfusion((W, H), (32, 32, 32), (4.8,) * 3, init, pyr)
+        ok = True
+        for f in range(2):          # two frames: the second one overwrites maps that hold stale values (SURVEY N3)
+            g.preprocessing(d); o.preprocessing(d)
+            g.tracking(k, 1e-5, 1, f); o.tracking(k, 1e-5, 1, f)
+            ok &= same_bits(g.buffer("floatDepth"), o.buffer("floatDepth"))
+            for l in range(len(pyr)):
+                ok &= same_bits(g.buffer("scaledDepth%d" % l), o.buffer("scaledDepth%d" % l))
+                ok &= same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l))
+                ok &= same_bits(g.buffer("inputNormal%d" % l)[..., :3], o.buffer("inputNormal%d" % l))
+            d = np.roll(d, 3, axis=1)
+        if verbose:
+            print("maps trial %2d  %dx%d ratio %d  pyramid %s  %s" % (trial, W, H, ratio, pyr, ok))
+        if not ok:
+            bad.append((trial, W, H, ratio, pyr))
+        g.close(); o.close()
+    return bad
+
+
 if __name__ == "__main__":
     import torch  # noqa: F401  (before the backend: one HIP runtime per process, see slambench_amd/_capi.py)
     from oracle import orc as _orc
@@ -65,6 +103,8 @@ if __name__ == "__main__":
     _orc.build()
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     trials = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    from slambench_amd import kfusion as _kf
     failures = run(_capi.lib(), _orc, seed, trials, verbose=True)
+    failures += run_maps(_kf, _orc, seed, max(4, trials // 4), verbose=True)
     print("trials %d, mismatches %d" % (trials, len(failures)))
     sys.exit(1 if failures else 0)

@@ -8,3 +8,8 @@ pytestmark = pytest.mark.gpu
 
 def test_random_volumes_and_poses(hip, orc):
     assert fuzz_parity.run(hip, orc, seed=20261003, trials=12) == []
+
+
+def test_random_depth_images_with_holes(hip, orc):
+    from slambench_amd import kfusion
+    assert fuzz_parity.run_maps(kfusion, orc, seed=20261003, trials=8) == []
