@@ -58,6 +58,55 @@ def run(hip, orc, seed=7, trials=12, verbose=False):
     return bad
 
 
+def run_track(hip, orc, seed=5, trials=8, verbose=False):
+    """The ICP association kernel (trackKernel, cpp:497-560) on the maps of a short oracle run, with the pose to test
+    perturbed at random (up to 3 degrees / 4 cm: pixels fall off the image, distance and normal tests flip): result codes,
+    errors and Jacobians of all pixels bit for bit, on every pyramid level."""
+    from tests.util import pad4
+    rng = np.random.default_rng(seed)
+    dev = Dev()
+    bad = []
+    for trial in range(trials):
+        W, H = [(160, 120), (128, 96)][trial % 2]
+        s = util.synth.make_stream(6, W, H, seed=int(rng.integers(1, 10 ** 6)), variant=int(rng.integers(0, 4)))
+        k = list(s.k)
+        o = orc.OracleKfusion((W, H), (64, 64, 64), (4.8,) * 3, s.init_pos, (4, 3, 2), omp=True)
+        for f in range(6):
+            o.preprocessing(s.depth_mm[f]); o.tracking(k, 1e-5, 1, f); o.integration(k, 1, 0.1, f); o.raycasting(k, 0.1, f)
+        refV, refN = o.buffer("vertex"), o.buffer("normal")
+        view = orc.matmul(orc.camera_matrix(s.k), orc.inverse(o.buffer("raycastPose")))
+        ok = True
+        for level in range(3):
+            inV, inN = o.buffer("inputVertex%d" % level), o.buffer("inputNormal%d" % level)
+            ih, iw = inV.shape[:2]
+            pose = o.get_pose().astype(np.float32).copy()
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            ang = rng.uniform(-0.05, 0.05)
+            Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+            pose[:3, :3] = (R @ pose[:3, :3]).astype(np.float32)
+            pose[:3, 3] += rng.uniform(-0.04, 0.04, 3).astype(np.float32)
+            ref = orc.track(inV, inN, refV, refN, pose, view)
+            out = dev.put(np.zeros((H, W), orc.TRACK_DTYPE).view(np.uint8))
+            hip.kfh_k_track(out.data_ptr(), dev.put(pad4(inV)).data_ptr(), dev.put(pad4(inN)).data_ptr(), iw, ih,
+                            dev.put(pad4(refV)).data_ptr(), dev.put(pad4(refN)).data_ptr(), W, H, m16(pose), m16(view), 0.1, 0.8, 1,
+                            dev.stream)
+            got = dev.get(out).view(orc.TRACK_DTYPE).reshape(H, W)
+            g_, r_ = got[:ih, :iw], ref[:ih, :iw]
+            good = r_["result"] == 1
+            ok &= bool(np.array_equal(g_["result"], r_["result"]) and same_bits(g_["error"][good], r_["error"][good])
+                       and same_bits(g_["J"][good], r_["J"][good]))
+            if verbose:
+                codes = {int(c): int((r_["result"] == c).sum()) for c in (1, -1, -2, -3, -4, -5)}
+                print("track trial %2d level %d  %dx%d  codes %s  %s" % (trial, level, iw, ih, codes, ok))
+        if not ok:
+            bad.append((trial, W, H))
+        o.close()
+        dev.clear()
+    return bad
+
+
 def run_maps(kfusion, orc, seed=11, trials=8, verbose=False):
     """Random depth images with holes (single zero pixels, zero blocks, depth steps) through preprocessing and the input
     pyramid of the pipeline: filtered depth, half-sampled depths, vertex maps and the validity of the normals, bit for bit."""
@@ -106,5 +155,6 @@ if __name__ == "__main__":
     from slambench_amd import kfusion as _kf
     failures = run(_capi.lib(), _orc, seed, trials, verbose=True)
     failures += run_maps(_kf, _orc, seed, max(4, trials // 4), verbose=True)
+    failures += run_track(_capi.lib(), _orc, seed, max(4, trials // 8), verbose=True)
     print("trials %d, mismatches %d" % (trials, len(failures)))
     sys.exit(1 if failures else 0)

@@ -13,3 +13,7 @@ def test_random_volumes_and_poses(hip, orc):
 def test_random_depth_images_with_holes(hip, orc):
     from slambench_amd import kfusion
     assert fuzz_parity.run_maps(kfusion, orc, seed=20261003, trials=8) == []
+
+
+def test_random_poses_through_the_association_kernel(hip, orc):
+    assert fuzz_parity.run_track(hip, orc, seed=20261003, trials=4) == []
