@@ -151,13 +151,22 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal on a one-GPU box: KFH_BENCH_BACKEND=gloo KFH_BENCH_ONE_DEVICE=1 runs the ranks side by side on cuda:0
+        # with the collective on the host (RCCL refuses two ranks on one device); the driver's runs use neither
+        backend = os.environ.get("KFH_BENCH_BACKEND", "nccl")
+        if os.environ.get("KFH_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
     else:
         torch.cuda.set_device(0)
         local_rank = 0
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    coll_device = "cuda" if (dist is None or os.environ.get("KFH_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
 
     cfg = CONFIGS[args.config]
     W, H, vres, pyramid, irate, zrate = cfg
@@ -184,7 +193,7 @@ def main():
 
     # whole-job aggregate: frames summed over ranks / max time over ranks (one small all-reduce on RCCL)
     job = multi.aggregate(multi.RankStats(args.steps * spg, elapsed, float(np.sum(errs)), float(np.max(errs)), int((tracked == 0).sum())),
-                          dist, device="cuda")
+                          dist, device=coll_device)
     t_max, total_frames = job.seconds, job.frames
     ate = {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs), "untracked_all_ranks": job.untracked}
 
@@ -192,7 +201,7 @@ def main():
     if not args.no_total:
         e2, kf2 = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, True, dist)
         kf2.close()
-        fps_total = multi.aggregate(multi.RankStats(args.steps, e2), dist, device="cuda").fps
+        fps_total = multi.aggregate(multi.RankStats(args.steps, e2), dist, device=coll_device).fps
 
     if rank != 0:
         if dist is not None:
