@@ -290,7 +290,7 @@ struct PyrGeom {
     static constexpr int offset = pyr_offset(NLEV, L);
 };
 
-template <int NLEV, int L>
+template <int NLEV, int L, int NTHR>
 __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
     using G = PyrGeom<NLEV, L>;
     const unsigned Wl = a.W >> L, Hl = a.H >> L;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
         using P = PyrGeom<NLEV, L - 1>;
         const float *dp = lds + P::offset;
         const int PX0 = ((bx * PYR_T) >> (L - 1)) - P::halo, PY0 = ((by * PYR_T) >> (L - 1)) - P::halo;
-        for (int idx = tid; idx < G::count; idx += PYR_THREADS) {
+        for (int idx = tid; idx < G::count; idx += NTHR) {
             const int ly = idx / G::stride, lx = idx - ly * G::stride;
             const int gx = X0 - G::halo + lx, gy = Y0 - G::halo + ly;
             if (gx < 0 || gy < 0 || gx >= (int)Wl || gy >= (int)Hl) continue;
@@ -323,7 +323,7 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
     }
     // vertex and normal maps of the tile (cpp:206-215, 225-247)
     const M4 invK = a.invK[L];
-    for (int idx = tid; idx < G::tile * G::tile; idx += PYR_THREADS) {
+    for (int idx = tid; idx < G::tile * G::tile; idx += NTHR) {
         const int ty = idx / G::tile, tx = idx - ty * G::tile;
         const int x = X0 + tx, y = Y0 + ty;
         if (x >= (int)Wl || y >= (int)Hl) continue;
@@ -339,26 +339,24 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
     }
 }
 
-// One 32x32 level-0 tile by a team of PYR_THREADS threads.  `tid` >= PYR_THREADS * 65536 marks an idle team: its loops
-// are empty and it only takes part in the barriers.
-template <int NLEV>
+// One 32x32 level-0 tile by the NTHR threads of a block.
+template <int NLEV, int NTHR>
 __device__ __forceinline__ void pyramid_block(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
     using G0 = PyrGeom<NLEV, 0>;
     // level-0 tile with halo; taps outside the image take the nearest pixel (only the 1-pixel ring is ever read there,
     // by the clamped neighbour accesses of the normals)
     const int X0 = bx * PYR_T - G0::halo, Y0 = by * PYR_T - G0::halo;
-    for (int idx = tid; idx < G0::count; idx += PYR_THREADS) {
+    for (int idx = tid; idx < G0::count; idx += NTHR) {
         const int ly = idx / G0::stride, lx = idx - ly * G0::stride;
         const int gx = imax(0, imin(X0 + lx, (int)a.W - 1)), gy = imax(0, imin(Y0 + ly, (int)a.H - 1));
         lds[idx] = a.scaled[0][gx + (size_t)gy * a.W];
     }
     __syncthreads();
-    pyramid_level<NLEV, 0>(a, lds, bx, by, tid);
-    if constexpr (NLEV > 1) pyramid_level<NLEV, 1>(a, lds, bx, by, tid);
-    if constexpr (NLEV > 2) pyramid_level<NLEV, 2>(a, lds, bx, by, tid);
-    if constexpr (NLEV > 3) pyramid_level<NLEV, 3>(a, lds, bx, by, tid);
+    pyramid_level<NLEV, 0, NTHR>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 1) pyramid_level<NLEV, 1, NTHR>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 2) pyramid_level<NLEV, 2, NTHR>(a, lds, bx, by, tid);
+    if constexpr (NLEV > 3) pyramid_level<NLEV, 3, NTHR>(a, lds, bx, by, tid);
 }
-constexpr int PYR_IDLE = 1 << 30;
 
 template <int NLEV>
 constexpr int pyr_lds_floats() { return PyrGeom<NLEV, NLEV - 1>::offset + PyrGeom<NLEV, NLEV - 1>::count; }
@@ -366,7 +364,7 @@ constexpr int pyr_lds_floats() { return PyrGeom<NLEV, NLEV - 1>::offset + PyrGeo
 template <int NLEV>
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid(PyramidArgs a) {
     __shared__ float lds[pyr_lds_floats<NLEV>()];
-    pyramid_block<NLEV>(a, lds, blockIdx.x, blockIdx.y, threadIdx.x);
+    pyramid_block<NLEV, PYR_THREADS>(a, lds, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 // =====================================================================================
@@ -762,8 +760,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
 
 // =====================================================================================
 // Dispatch order of the raycast tiles for the next frame (see k_raycast): counting sort, most expensive first, of each
-// tile's cost dilated over its eight neighbours (a silhouette ray that just misses an object marches four times longer
-// than its neighbour that hits it, and which tile holds it changes with every camera step).  Ties go in any order - the
+// tile's cost (which k_raycast has already dilated over the eight neighbours).  Ties go in any order - the
 // order is a scheduling hint, never an input of the computation.  One 1024-thread block; `cost` holds n raw costs
 // (cleared here) followed by n sort keys.  Runs as a side block of the first ICP launch of the next frame, or alone.
 // =====================================================================================
@@ -772,14 +769,13 @@ constexpr int RAY_COST_BUCKETS = 64;               // cost classes (raycast: 4 m
 #define KFH_RAY_SUPER_SHIFT 3
 #endif
 constexpr int RAY_REGIONS = 8;                     // = XCDs: launch slot s runs on the XCD that all slots = s (mod 8) share
-constexpr unsigned RAY_ORDER_LDS_TILES = 8192;     // costs of up to this many tiles are staged in LDS
+constexpr unsigned RAY_ORDER_KEPT_TILES = 8192;
 struct RayOrderShared {
     unsigned hist[RAY_REGIONS][RAY_COST_BUCKETS], scan[RAY_REGIONS][RAY_COST_BUCKETS], offs[RAY_REGIONS][RAY_COST_BUCKETS];
-    unsigned cost[RAY_ORDER_LDS_TILES];
     unsigned count[RAY_REGIONS];
 };
 
-// mode 0: raycast tiles (costs dilated over the 8 neighbours, 4 cost units per bucket); mode 1: integrate blocks (plain).
+// mode 0: raycast tiles (4 cost units per bucket, XCD classes); mode 1: integrate blocks (one class).
 // XCD affinity (mode 0): workgroups are dealt round-robin over the 8 XCDs, each with its own L2, so the screen is cut into
 // super-tiles of 8x8 tiles (64x64 pixels) that are dealt to 8 classes like a chess board; class k is sorted by cost on
 // its own and gets the launch slots k, k + 8, k + 16, ... (as long as every class has tiles left): the rays of a
@@ -790,29 +786,20 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
                                                 unsigned tiles_x, unsigned tiles_y, unsigned mode) {
     const unsigned n = tiles_x * tiles_y, tid = threadIdx.x, nthr = blockDim.x;
     unsigned *key = cost + n;
-    const bool staged = n <= RAY_ORDER_LDS_TILES;
+    const bool staged = n <= RAY_ORDER_KEPT_TILES;
     const unsigned R = mode == 0 ? RAY_REGIONS : 1u;
     constexpr int SS = KFH_RAY_SUPER_SHIFT;                 // super-tile edge = 1 << SS tiles
     const unsigned super_x = (tiles_x + (1u << SS) - 1) >> SS;
     for (unsigned i = tid; i < RAY_REGIONS * RAY_COST_BUCKETS; i += nthr) (&sh.hist[0][0])[i] = 0;      // (nthr = 1024)
-    if (staged) for (unsigned i = tid; i < n; i += nthr) sh.cost[i] = cost[i];
     __syncthreads();
-    const unsigned *src = staged ? sh.cost : cost;
     const float inv_tx = 1.0f / (float)tiles_x;
-    constexpr int KEEP = RAY_ORDER_LDS_TILES / 1024;      // keys of a staged sort stay in registers between the passes
+    constexpr int KEEP = RAY_ORDER_KEPT_TILES / 1024;     // keys of up to this many tiles stay in registers between the passes
     unsigned keys[KEEP];
     int slot = 0;
     for (unsigned i = tid; i < n; i += nthr, ++slot) {
         const int ty = (int)(((float)i + 0.5f) * inv_tx), tx = (int)i - ty * (int)tiles_x;   // exact: i < 2^23
-        unsigned m = src[i];
-        if (mode == 0) {
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int x = tx + dx, y = ty + dy;
-                    if (x >= 0 && y >= 0 && x < (int)tiles_x && y < (int)tiles_y) { const unsigned c = src[x + y * tiles_x]; m = m > c ? m : c; }
-                }
-            m >>= 2;
-        }
+        unsigned m = cost[i];
+        if (mode == 0) m >>= 2;
         const unsigned b = m < RAY_COST_BUCKETS - 1 ? m : RAY_COST_BUCKETS - 1;
         const unsigned r = R == 1 ? 0u : ((unsigned)(tx >> SS) + super_x * (unsigned)(ty >> SS) + (unsigned)(ty >> SS)) % RAY_REGIONS;
         const unsigned k = b | (r << 8);        // (b < 256)
@@ -986,20 +973,17 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
 template <int NLEV>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
     __shared__ IcpShared sh;
-    __shared__ float lds[SIDE_TEAMS][pyr_lds_floats<NLEV>()];
+    __shared__ float lds[pyr_lds_floats<NLEV>()];
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
     if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
-    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
-    const unsigned rounds = (sp.count + nside * SIDE_TEAMS - 1) / (nside * SIDE_TEAMS);
-    for (unsigned r = 0; r < rounds; ++r) {
-        const unsigned i = (r * SIDE_TEAMS + team) * nside + side;
-        const bool active = i < sp.count;
+    // all 1024 threads on one tile at a time (one pixel each at level 0): there are about as many tiles as side blocks
+    for (unsigned i = side; i < sp.count; i += nside) {
         const unsigned t = sp.first + i;
-        pyramid_block<NLEV>(sp.a, lds[team], (int)(t % tiles_x), (int)(t / tiles_x), active ? tid : PYR_IDLE);
+        pyramid_block<NLEV, ICP_THREADS>(sp.a, lds, (int)(t % tiles_x), (int)(t / tiles_x), (int)threadIdx.x);
         __syncthreads();
     }
 }
@@ -1674,7 +1658,13 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     if (sg.cost || sg.trace) {   // the longest march of the wave, kept per tile for the next frame's dispatch order
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) work = imax(work, __shfl_xor(work, off, 64));
-        if (sg.cost && (threadIdx.x & 63) == 0) atomicMax(sg.cost + tile, (unsigned)work);
+        // ... dilated over the eight neighbours here, by nine lanes of one atomic instruction, so that the sort reads one
+        // number per tile: a silhouette ray that just misses an object marches four times longer than its neighbour that
+        // hits it, and which tile holds it changes with every camera step
+        const int lane = (int)(threadIdx.x & 63u);
+        const int nx = (int)(tile % gridDim.x) + lane % 3 - 1, ny = (int)(tile / gridDim.x) + lane / 3 - 1;
+        if (sg.cost && lane < 9 && nx >= 0 && ny >= 0 && nx < (int)gridDim.x && ny < (int)gridDim.y)
+            atomicMax(sg.cost + nx + ny * (int)gridDim.x, (unsigned)work);
     }
     if (sg.trace && (threadIdx.x & 63) == 0) {
         const unsigned wave = slot * 4 + (threadIdx.x >> 6);
