@@ -169,6 +169,8 @@ def main():
     coll_device = "cuda" if (dist is None or os.environ.get("KFH_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
 
     cfg = CONFIGS[args.config]
+    if os.environ.get("KFH_DEBUG_PYRAMID"):    # experiments only (cost of the queued-but-empty ICP launches)
+        cfg = cfg[:3] + (tuple(int(v) for v in os.environ["KFH_DEBUG_PYRAMID"].split(",")),) + cfg[4:]
     W, H, vres, pyramid, irate, zrate = cfg
     n_frames = args.warmup + args.steps
     # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])

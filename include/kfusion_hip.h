@@ -122,6 +122,9 @@ void kfh_icp_level_iterations(kfh_context *ctx, uint64_t out[KFH_MAX_LEVELS]);
 uint64_t kfh_integrate_updated(kfh_context *ctx);
 /* ICP solves whose normal equations were too ill-conditioned for the LDL^T fast path (device counter). */
 uint64_t kfh_solve_fallbacks(kfh_context *ctx);
+/* Workgroups that gave up waiting at the grid barrier of the shared late-iteration ICP launch (device counter; stays 0
+ * unless other work hogs the device for seconds - a frame it happened in is not to be trusted). */
+uint64_t kfh_barrier_timeouts(kfh_context *ctx);
 
 /* Per-phase device time from HIP events recorded on the context's stream around each launch group
  * (the role of the reference's KERNEL_TIMINGS TICK/TOCK, cpp/kernels.cpp:31-35).  phase_mask has bit

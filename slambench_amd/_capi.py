@@ -53,6 +53,7 @@ SIGNATURES = {
     "kfh_icp_level_iterations": (None, [vp, C.POINTER(C.c_uint64)]),
     "kfh_integrate_updated": (u64, [vp]),
     "kfh_solve_fallbacks": (u64, [vp]),
+    "kfh_barrier_timeouts": (u64, [vp]),
     "kfh_set_profiling": (None, [vp, u]),
     "kfh_set_profiling_stride": (None, [vp, u]),
     "kfh_read_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

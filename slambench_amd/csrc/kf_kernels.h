@@ -30,6 +30,8 @@ struct DevState {
     unsigned long long integrate_updated;   // U of SURVEY §8(d), summed over all integrate launches
     unsigned long long solve_fallbacks;     // ICP solves that needed the Jacobi path (ill-conditioned J^T J)
     unsigned long long icp_level_iterations[KFH_MAX_LEVELS];   // icp_iterations by pyramid level
+    unsigned tail_barrier[KFH_MAX_LEVELS];   // arrival counters of k_icp_tail's grid barrier (zero between frames)
+    unsigned barrier_timeouts;               // workgroups that gave up waiting there (never, unless the device is hogged)
 };
 
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran
@@ -121,6 +123,11 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
               float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s);
+// the last n_its iterations of a level (it .. it + n_its - 1, all after an ordinary launch of that level) in one launch
+void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
+              unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
+              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
+              hipStream_t s);
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

@@ -707,8 +707,11 @@ struct IcpShared {
 
 // Brings `sh` to the state entering iteration `it`: pose and flags after the update of iteration it-1.
 #define ICP_STAMP(i) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[i] = __builtin_readcyclecounter(); } while (0)
-__device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *__restrict__ iters,
-                                            const float *__restrict__ partials_prev, int it, int prev_level,
+// COHERENT: the state record and the partial sums were written by other workgroups of THIS launch (k_icp_tail, after its
+// grid barrier), so they are read with agent-scope atomic loads, which no cache of this CU or XCD may serve stale.
+template <bool COHERENT = false>
+__device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *iters,
+                                            const float *partials_prev, int it, int prev_level,
                                             unsigned prev_nblocks, float icp_threshold, bool writer,
                                             unsigned long long *trace = nullptr) {
     ICP_STAMP(0);
@@ -718,7 +721,15 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = st->level_done[l];
             sh.prev_executed = 0;
         } else {
-            const IcpState prev = iters[it - 1];
+            IcpState prev;
+            if (COHERENT) {
+                static_assert(sizeof(IcpState) % 4 == 0, "word-wise copy");
+                const unsigned *src = reinterpret_cast<const unsigned *>(iters + (it - 1));
+                unsigned *dst = reinterpret_cast<unsigned *>(&prev);
+                for (unsigned w = 0; w < sizeof(IcpState) / 4; ++w) dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                prev = iters[it - 1];
+            }
             sh.pose = prev.pose;
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = prev.done[l];
             sh.prev_executed = prev.executed;
@@ -730,7 +741,8 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     constexpr int G = ICP_THREADS / 32;
     float acc = 0.f;
-    for (unsigned b = g; b < prev_nblocks; b += G) acc += partials_prev[(size_t)b * 32 + c];
+    for (unsigned b = g; b < prev_nblocks; b += G)
+        acc += COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
     sh.sm[g][c] = acc;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -869,16 +881,16 @@ struct IcpIterArgs {
     unsigned ray_tiles_x, ray_tiles_y, order_mode;
 };
 
-__device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs &a) {
+// state entering iteration `it` (solve of iteration it-1 included), recorded by the writer block; true if `it` is to run
+template <bool COHERENT = false>
+__device__ __forceinline__ bool icp_enter(IcpShared &sh, const IcpIterArgs &a, int it, const float *partials_prev, bool writer) {
     DevState *__restrict__ st = a.st;
-    IcpState *__restrict__ iters = a.iters;
-    const bool writer = blockIdx.x == 0;
     unsigned long long *trace = a.trace;
-    icp_advance(sh, st, iters, a.partials_prev, a.it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer, trace);
+    icp_advance<COHERENT>(sh, st, a.iters, partials_prev, it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer, trace);
     if (threadIdx.x == 0) {
         sh.executed = sh.done[a.level] ? 0 : 1;
         if (writer) {
-            IcpState &o = iters[a.it];
+            IcpState &o = a.iters[it];
             o.pose = sh.pose;
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
             o.executed = sh.executed;
@@ -886,7 +898,13 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
     }
     __syncthreads();
     ICP_STAMP(4);
-    if (!sh.executed) return;
+    return sh.executed != 0;
+}
+
+// association + partial sums of ICP block `vb` (of a.nblocks) with the pose in sh
+__device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs &a, unsigned vb, float *partials_out) {
+    DevState *__restrict__ st = a.st;
+    unsigned long long *trace = a.trace;
     const M4 T = sh.pose;
     const M4 view = st->track.view;
     const int have_reference = st->track.have_reference;
@@ -896,7 +914,7 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
     const unsigned n = a.inW * a.inH;
     const float4 *__restrict__ inV = a.inV, *__restrict__ inN = a.inN, *__restrict__ refV = a.refV, *__restrict__ refN = a.refN;
     int *__restrict__ result_map = a.result_map;
-    for (unsigned p = blockIdx.x * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
+    for (unsigned p = vb * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
         const unsigned py = p / a.inW, px = p - py * a.inW;
         const PixelTrack r = track_pixel(px, py, inV, inN, a.inW, refV, refN, a.refW, a.refH, T, view, have_reference,
                                          a.dist_threshold, a.normal_threshold);
@@ -904,8 +922,13 @@ __device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs 
         accumulate(acc, r.result, r.error, r.J);
     }
     ICP_STAMP(5);
-    block_reduce_store<ICP_THREADS>(acc, a.partials_out + (size_t)blockIdx.x * 32);
+    block_reduce_store<ICP_THREADS>(acc, partials_out + (size_t)vb * 32);
     ICP_STAMP(6);
+}
+
+__device__ __forceinline__ void icp_iter_block(IcpShared &sh, const IcpIterArgs &a) {
+    if (!icp_enter(sh, a, a.it, a.partials_prev, blockIdx.x == 0)) return;
+    icp_track_block(sh, a, blockIdx.x, a.partials_out);
 }
 
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter(IcpIterArgs a) {
@@ -919,6 +942,63 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_or
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
+}
+
+// ---- tail launch --------------------------------------------------------------------------------------------------
+// The late iterations of a level are queued for the worst case but almost never run (640x480 living room: level 0 stops
+// after 3 of its 10 iterations in 91 % of the frames, after 4 in 7 %), and an empty launch still costs ~2 us of queue
+// time.  k_icp_tail runs the last `n_its` iterations of a level in ONE launch: a few workgroups (at most ICP_TAIL_BLOCKS,
+// few enough to be resident together whatever else the device runs) loop over the iterations, each emulating the
+// a.nblocks ICP blocks of an ordinary launch in turn - same pixels per block, same partial rows, same sums, hence the
+// same bits - with a grid barrier between iterations (release/acquire on a counter in DevState; the partial sums and the
+// state record are re-read with agent-scope loads).  All workgroups take the same decisions from the same data, so they
+// leave together as soon as the level has converged, and block 0 fills in the records of the iterations that were not
+// needed.  An iteration that does run here is several times slower than in a launch of its own; the schedule keeps the
+// first ICP_TAIL_HEAD iterations of a level in ordinary launches so that this is rare.
+// A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
+// time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
+constexpr unsigned ICP_TAIL_BLOCKS = 32;
+struct IcpTailArgs { float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts; };
+
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, unsigned *timeouts) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                    // release: this workgroup's partial rows / state record
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();       // 100 MHz
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < goal) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000000ull) { atomicAdd(timeouts, 1u); break; }
+        }
+        __threadfence();                                    // acquire
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(IcpIterArgs a, IcpTailArgs t) {
+    __shared__ IcpShared sh;
+    const bool writer = blockIdx.x == 0;
+    for (int j = 0; j < t.n_its; ++j) {
+        const int it = a.it + j;
+        const float *prev = t.part[(it + 1) & 1];
+        const bool run = j == 0 ? icp_enter<false>(sh, a, it, prev, writer) : icp_enter<true>(sh, a, it, prev, writer);
+        if (!run) {
+            // the level is done: the remaining iterations would only hand the state on (as their launches did)
+            if (writer && threadIdx.x == 0)
+                for (int k = it + 1; k < a.it + t.n_its; ++k) {
+                    IcpState &o = a.iters[k];
+                    o.pose = sh.pose;
+                    for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+                    o.executed = 0;
+                }
+            return;
+        }
+        for (unsigned vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
+            icp_track_block(sh, a, vb, t.part[it & 1]);
+            __syncthreads();                                // block_reduce_store's LDS rows are reused
+        }
+        if (j + 1 < t.n_its) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts);
+    }
 }
 
 // ---- side jobs ----------------------------------------------------------------------------------------------------
@@ -999,7 +1079,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
     icp_advance(sh, st, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, true);
     if (threadIdx.x == 0) {
         st->pose = sh.pose;
-        for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = sh.done[l];
+        for (int l = 0; l < KFH_MAX_LEVELS; ++l) { st->level_done[l] = sh.done[l]; st->tail_barrier[l] = 0; }
         control_ops(st, log, ops, a);
     }
 }
@@ -2001,6 +2081,20 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         return;
     }
     k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a);
+}
+
+void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
+              unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
+              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
+              hipStream_t s) {
+    // (the launch before `it` is an ordinary one of the same level: prev_level = level, prev_nblocks = nblocks)
+    IcpIterArgs a = make_icp_args(st, iters, (it + 1) & 1 ? part1 : part0, it & 1 ? part1 : part0, result_map, it, level, level,
+                                  nblocks, nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
+                                  normal_threshold);
+    IcpTailArgs t;
+    t.part[0] = part0; t.part[1] = part1; t.n_its = n_its;
+    t.barrier = &st->tail_barrier[level]; t.timeouts = &st->barrier_timeouts;
+    k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t);
 }
 
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,

@@ -63,6 +63,7 @@ struct kfh_context {
     float *alt_floatDepth = nullptr;
     std::vector<float *> alt_scaled;
     std::vector<float4 *> alt_inV, alt_inN;
+    std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
         bool valid = false;
@@ -270,6 +271,15 @@ static void fill_side_pyramid(const kfh_context *c, const NextFrameWork &nw, Sid
     }
 }
 
+// How many of a level's last iterations share one launch (k_icp_tail): everything after the first `icp_tail_head`
+// (KFH_ICP_TAIL_HEAD, one value or a list by level, default 4; 0 = every iteration gets its own launch), if that is at least two.
+static int tail_length(const kfh_context *c, int level) {
+    const int n = c->iterations[level];
+    const int head = c->icp_tail_head.empty() ? 4 : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
+    if (head <= 0 || n - head < 2) return 0;
+    return n - head;
+}
+
 // Queues the pyramid (unless `pyramid_ready`) and the whole ICP loop.  `end_ops` are the control operations that follow
 // tracking; they ride on the launch that applies the last ICP update (or on a plain control launch when this frame is
 // not tracked).  `next`, if given, is the next frame's input work: it is spread over the first ICP launches of the
@@ -309,8 +319,17 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
         bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
         int last = -1;
-        for (int v : bil_its) { ok = ok && v > last && v < coarse_launches; last = v; }
-        for (int v : pyr_its) { ok = ok && v > last && v < coarse_launches; last = v; }
+        auto plain_launch = [&](int v) {    // iteration v has a launch of its own (is not folded into a level's tail launch)
+            int first = 0;
+            for (int level = L - 1; level >= 0; --level) {
+                const int n = c->iterations[level] > 0 ? c->iterations[level] : 0;
+                if (v < first + n) return tail_length(c, level) == 0 || v - first < n - tail_length(c, level);
+                first += n;
+            }
+            return false;
+        };
+        for (int v : bil_its) { ok = ok && v > last && v < coarse_launches && plain_launch(v); last = v; }
+        for (int v : pyr_its) { ok = ok && v > last && v < coarse_launches && plain_launch(v); last = v; }
         if (!ok) { bil_its.clear(); pyr_its.clear(); }
     }
     const bool placed = next && !bil_its.empty();
@@ -323,7 +342,8 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     for (int level = L - 1; level >= 0; --level) {   // cpp:950-967
         const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
         const unsigned nb = launch::icp_blocks(w, h);
-        for (int i = 0; i < c->iterations[level]; ++i) {
+        const int n_tail = tail_length(c, level), n_plain = c->iterations[level] - n_tail;
+        for (int i = 0; i < n_plain; ++i) {
             SideWork side;
             const SideWork *sp = nullptr;
             for (size_t j = 0; placed && j < bil_its.size(); ++j)
@@ -358,6 +378,12 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
                              dist_threshold, normal_threshold, sp, c->stream);
             prev_level = level; prev_nb = nb; ++it;
+        }
+        if (n_tail > 0) {   // the rarely needed late iterations of the level, one launch (k_icp_tail)
+            launch::icp_tail(c->d_state, c->d_icp, part[0], part[1], c->d_result, it, n_tail, level, nb, c->d_inV[level],
+                             c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold, dist_threshold,
+                             normal_threshold, c->stream);
+            it += n_tail;
         }
     }
     if (it > 0) launch::icp_final(c->d_state, c->d_log, c->d_icp, part[(it + 1) & 1], it, prev_level, prev_nb, icp_threshold, end_ops, a, c->stream);
@@ -532,6 +558,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_normal, P * sizeof(float4)));
     ok &= HIP_TRY(hipMalloc(&c->d_result, P * sizeof(int)));
     ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float)));
+    c->icp_tail_head = parse_int_list(getenv("KFH_ICP_TAIL_HEAD"));
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
     ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
@@ -824,6 +851,7 @@ int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracke
 }
 
 uint64_t kfh_solve_fallbacks(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->solve_fallbacks; }
+uint64_t kfh_barrier_timeouts(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->barrier_timeouts; }
 uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
 
 void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {

@@ -162,6 +162,9 @@ class Kfusion:
     def solve_fallbacks(self):
         return int(self.L.kfh_solve_fallbacks(self.h))
 
+    def barrier_timeouts(self):
+        return int(self.L.kfh_barrier_timeouts(self.h))
+
     def integrate_updated(self):
         return int(self.L.kfh_integrate_updated(self.h))
 

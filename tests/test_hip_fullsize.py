@@ -126,6 +126,33 @@ np.savez(sys.argv[1], pose=g.get_pose(), vertex=g.buffer("vertex"), normal=g.buf
 """
 
 
+@pytest.mark.parametrize("icp_threshold", [util.ICP_THRESHOLD, 0.0])
+def test_shared_late_iteration_launch_equals_one_launch_per_iteration(hip, kfmod, stream, monkeypatch, icp_threshold):
+    """k_icp_tail runs the late iterations of a pyramid level in one launch, a few workgroups emulating the blocks of an
+    ordinary launch with a grid barrier between iterations.  It must leave the bits one launch per iteration leaves -
+    poses, flags, track result, iteration counts - when the level converges early (the common case: the tail only
+    detects it) and when every queued iteration runs (threshold 0: 6 + 1 x 9 iterations inside tail launches)."""
+    k = list(stream.k)
+    res = (128, 128, 128)
+    runs = {}
+    for head in ("0", "4", "1"):      # 0: no tail launches; 1: every level's iterations 1.. share a launch
+        monkeypatch.setenv("KFH_ICP_TAIL_HEAD", head)
+        g = kfmod.Kfusion((W, H), res, util.VOL_DIM, stream.init_pos)
+        for f in range(FRAMES):
+            g.compute_frame(stream.depth_mm[f], (W, H), k, 1, 1, icp_threshold, util.MU, f)
+        poses, tracked, integrated = g.frame_log(FRAMES)
+        assert g.barrier_timeouts() == 0
+        runs[head] = (poses.copy(), list(tracked), list(integrated), g.buffer("trackResult").copy(), g.icp_level_iterations(),
+                      g.buffer("volume").copy())
+        g.close()
+    if icp_threshold == 0.0:
+        assert runs["0"][4] == [10 * (FRAMES - 0), 5 * FRAMES, 4 * FRAMES]
+    for head in ("4", "1"):
+        assert same_bits(runs["0"][0], runs[head][0]), head
+        assert runs["0"][1:3] == runs[head][1:3] and runs["0"][4] == runs[head][4], head
+        assert np.array_equal(runs["0"][3], runs[head][3]) and np.array_equal(runs["0"][5], runs[head][5]), head
+
+
 def test_ray_march_variants_agree(hip, tmp_path):
     """Lanes per ray (1, 2, 4, 8), empty-space skipping, the cost-ordered tile dispatch, the division by reciprocal and
     the queued-frame pipelining are performance knobs only: every variant must reproduce the same bits (each runs in its
