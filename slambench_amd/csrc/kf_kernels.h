@@ -123,11 +123,12 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
               float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s);
-// the last n_its iterations of a level (it .. it + n_its - 1, all after an ordinary launch of that level) in one launch
+// the last n_its iterations of a level (it .. it + n_its - 1, all after an ordinary launch of that level) in one launch;
+// if it is the last launch of the frame's loop it can apply the final update and the control operations too
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              hipStream_t s);
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, hipStream_t s);   // ca != nullptr: also does icp_final's work
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

@@ -720,6 +720,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
             sh.pose = st->pose;
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = st->level_done[l];
             sh.prev_executed = 0;
+            if (writer) for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->tail_barrier[l] = 0;   // (k_icp_tail's counters: no launch of it is running)
         } else {
             IcpState prev;
             if (COHERENT) {
@@ -944,6 +945,16 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_or
     ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
 }
 
+// End of a frame's ICP loop (one thread of the closing launch): final pose and flags, then the control operations that
+// follow tracking.  (Staging the head of DevState in LDS for this scalar glue was tried: no gain, the chain is arithmetic.)
+__device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, FrameLogEntry *log, int ops, const ControlArgs &ca) {
+    if (threadIdx.x == 0) {
+        st->pose = sh.pose;
+        for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = sh.done[l];
+        control_ops(st, log, ops, ca);
+    }
+}
+
 // ---- tail launch --------------------------------------------------------------------------------------------------
 // The late iterations of a level are queued for the worst case but almost never run (640x480 living room: level 0 stops
 // after 3 of its 10 iterations in 91 % of the frames, after 4 in 7 %), and an empty launch still costs ~2 us of queue
@@ -958,7 +969,11 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_or
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
 constexpr unsigned ICP_TAIL_BLOCKS = 32;
-struct IcpTailArgs { float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts; };
+struct IcpTailArgs {
+    float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
+    int final_ops;            // >= 0: the launch closes the frame's ICP loop with these control operations (k_icp_final's job)
+    FrameLogEntry *log; ControlArgs ca;
+};
 
 __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, unsigned *timeouts) {
     __syncthreads();
@@ -978,27 +993,37 @@ __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, u
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(IcpIterArgs a, IcpTailArgs t) {
     __shared__ IcpShared sh;
     const bool writer = blockIdx.x == 0;
-    for (int j = 0; j < t.n_its; ++j) {
+    const bool closes = t.final_ops >= 0;       // this launch also does k_icp_final's work (block 0, after the loop)
+    for (int j = 0; j <= t.n_its; ++j) {
         const int it = a.it + j;
         const float *prev = t.part[(it + 1) & 1];
+        if (j == t.n_its) {
+            // every queued iteration ran (rare): the update of the last one, as k_icp_final would apply it
+            if (!(closes && writer)) return;
+            icp_advance<true>(sh, a.st, a.iters, prev, it, a.level, a.nblocks, a.icp_threshold, true);
+            break;
+        }
         const bool run = j == 0 ? icp_enter<false>(sh, a, it, prev, writer) : icp_enter<true>(sh, a, it, prev, writer);
         if (!run) {
             // the level is done: the remaining iterations would only hand the state on (as their launches did)
-            if (writer && threadIdx.x == 0)
-                for (int k = it + 1; k < a.it + t.n_its; ++k) {
-                    IcpState &o = a.iters[k];
-                    o.pose = sh.pose;
-                    for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-                    o.executed = 0;
-                }
-            return;
+            if (!writer) return;
+            if ((int)threadIdx.x < a.it + t.n_its - (it + 1)) {     // one thread per record
+                IcpState &o = a.iters[it + 1 + (int)threadIdx.x];
+                o.pose = sh.pose;
+                for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+                o.executed = 0;
+            }
+            if (!closes) return;
+            break;
         }
         for (unsigned vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
             icp_track_block(sh, a, vb, t.part[it & 1]);
             __syncthreads();                                // block_reduce_store's LDS rows are reused
         }
-        if (j + 1 < t.n_its) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts);
+        if (j + 1 < t.n_its || closes) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts);
     }
+    // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
+    close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
 }
 
 // ---- side jobs ----------------------------------------------------------------------------------------------------
@@ -1077,11 +1102,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
                                                           int ops, ControlArgs a) {
     __shared__ IcpShared sh;
     icp_advance(sh, st, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, true);
-    if (threadIdx.x == 0) {
-        st->pose = sh.pose;
-        for (int l = 0; l < KFH_MAX_LEVELS; ++l) { st->level_done[l] = sh.done[l]; st->tail_barrier[l] = 0; }
-        control_ops(st, log, ops, a);
-    }
+    close_icp_loop(sh, st, log, ops, a);
 }
 
 // =====================================================================================
@@ -2086,7 +2107,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              hipStream_t s) {
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, hipStream_t s) {
     // (the launch before `it` is an ordinary one of the same level: prev_level = level, prev_nblocks = nblocks)
     IcpIterArgs a = make_icp_args(st, iters, (it + 1) & 1 ? part1 : part0, it & 1 ? part1 : part0, result_map, it, level, level,
                                   nblocks, nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
@@ -2094,6 +2115,8 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     IcpTailArgs t;
     t.part[0] = part0; t.part[1] = part1; t.n_its = n_its;
     t.barrier = &st->tail_barrier[level]; t.timeouts = &st->barrier_timeouts;
+    t.final_ops = ca ? final_ops : -1; t.log = log;
+    if (ca) t.ca = *ca; else t.ca = ControlArgs{};
     k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t);
 }
 

@@ -339,6 +339,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     float *part[2] = {c->d_partials, c->d_partials + (size_t)launch::track_blocks_max() * 32};
     int it = 0, prev_level = 0;
     unsigned prev_nb = 0;
+    bool closed = false;
     for (int level = L - 1; level >= 0; --level) {   // cpp:950-967
         const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
         const unsigned nb = launch::icp_blocks(w, h);
@@ -380,13 +381,16 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             prev_level = level; prev_nb = nb; ++it;
         }
         if (n_tail > 0) {   // the rarely needed late iterations of the level, one launch (k_icp_tail)
+            static const bool fold_env = [] { const char *e = getenv("KFH_ICP_TAIL_CLOSES"); return !(e && e[0] == '0'); }();
+            closed = level == 0 && fold_env;      // the loop's last launch: it applies the final update and end_ops too
             launch::icp_tail(c->d_state, c->d_icp, part[0], part[1], c->d_result, it, n_tail, level, nb, c->d_inV[level],
                              c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold, dist_threshold,
-                             normal_threshold, c->stream);
+                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, c->stream);
             it += n_tail;
         }
     }
-    if (it > 0) launch::icp_final(c->d_state, c->d_log, c->d_icp, part[(it + 1) & 1], it, prev_level, prev_nb, icp_threshold, end_ops, a, c->stream);
+    if (closed) {}
+    else if (it > 0) launch::icp_final(c->d_state, c->d_log, c->d_icp, part[(it + 1) & 1], it, prev_level, prev_nb, icp_threshold, end_ops, a, c->stream);
     else launch::control(c->d_state, c->d_log, end_ops, a, c->stream);
     prof_end(c, KFH_PROF_ICP);
     return placed;
