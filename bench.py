@@ -41,6 +41,17 @@ CONFIGS = {
 MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, float(os.environ.get("KFH_DEBUG_ICP_THRESHOLD", "1e-5")), 1
 
 
+def icp_launches(pyramid, head=4):
+    """launches of a frame's ICP loop: per level the first `head` iterations one each, the rest (if >= 2) share one
+    (kf_pipeline.hip tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
+    n, closed = 0, False
+    for level, its in enumerate(pyramid):
+        tail = its - head if its - head >= 2 else 0
+        n += its - tail + (1 if tail else 0)
+        closed = closed or (tail > 0 and level == 0)
+    return n + (0 if closed else 1)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,8 +235,9 @@ def main():
             for short in ("integrate", "raycast"):
                 if ("k_" + short) in kname:
                     traffic[short] = v["hbm_bytes_per_launch"]
-        # the ICP loop of a frame = all k_icp_iter* launches + k_icp_final (+ k_control when it is a launch of its own)
-        frames_t = sum(v["launches"] for kname, v in tj.items() if "k_icp_final" in kname)
+        # the ICP loop of a frame = all k_icp_iter* / k_icp_tail / k_icp_final launches (+ k_control when it is a launch of
+        # its own); frames of the run = launches of k_raycast (one per frame)
+        frames_t = sum(v["launches"] for kname, v in tj.items() if "k_raycast" in kname)
         loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
         if frames_t and loop_t:
             traffic["icp"] = round(loop_t / frames_t)
@@ -244,7 +256,7 @@ def main():
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n, "sampled_every_n_frames": args.profile_every,
                       "algorithmic_bytes_per_launch": round(alg)}
-    # The ICP loop of a frame (19 launches of k_icp_iter*, k_icp_final): 48 bytes per associated pixel (two float4 input
+    # The ICP loop of a frame (k_icp_iter* launches, k_icp_tail for the late iterations of a level, k_icp_final): 48 bytes per associated pixel (two float4 input
     # maps, a 32-byte gather from the reference maps) for every EXECUTED iteration, plus - on the queued-frame path - the
     # next frame's bilateral filter (2P in, 8P out) and pyramid (4P in, 36 bytes per pixel of every level out) that ride
     # on it.  One "launch" of this entry is one frame's loop.
@@ -256,7 +268,7 @@ def main():
         alg += 10.0 * P + 4.0 * P + 36.0 * sum(px)
         avg_s = ms / n * 1e-3
         gbs = alg / avg_s / 1e9
-        roof["icp"] = {"kernel": "k_icp_iter* + k_icp_final (one frame's ICP loop, %d launches)" % (sum(pyramid) + 1), "bound": "hbm",
+        roof["icp"] = {"kernel": "k_icp_iter* + k_icp_tail (one frame's ICP loop: %d queued iterations in %d launches)" % (sum(pyramid), icp_launches(pyramid)), "bound": "hbm",
                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                        "traffic": traffic.get("icp"), "avg_us": round(avg_s * 1e6, 2), "launches": n,
                        "sampled_every_n_frames": args.profile_every, "algorithmic_bytes_per_launch": round(alg),

@@ -41,7 +41,7 @@ def main(out):
             "hbm_bytes_per_launch_raw": round((f_kib + w_kib) * 1024),
             "hbm_bytes_per_launch": round((2 * f_kib + w_kib) * 1024),
             # over ALL launches of the run (the ICP loop is many launches of several kernels: bench.py adds these up
-            # and divides by the frames of the run, i.e. the launches of k_icp_final)
+            # and divides by the frames of the run, i.e. the launches of k_raycast)
             "hbm_bytes_total": round((2 * sum(f) + sum(w)) * 1024),
         }
     json.dump(res, open(out + "/traffic.json", "w"), indent=1)

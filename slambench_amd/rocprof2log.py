@@ -25,7 +25,7 @@ NAMES = [
     (r"k_depth2vertex", "depth2vertexKernel"),
     (r"k_vertex2normal|k_vertex_normal", "vertex2normalKernel"),
     (r"k_pyramid", "pyramidKernel"),
-    (r"k_icp_iter|k_icp_final|k_track_reduce|k_control", "trackKernel"),
+    (r"k_icp_iter|k_icp_tail|k_icp_final|k_track_reduce|k_control", "trackKernel"),
     (r"k_reduce_trackdata|k_solve", "reduceKernel"),
     (r"k_update_pose|k_check_pose", "updatePoseKernel"),
     (r"k_integrate", "integrateKernel"),
