@@ -1403,8 +1403,7 @@ __device__ __forceinline__ void tap_pair(const V &v, int p, int y, int z, bool l
 }
 
 template <class V>
-__device__ __forceinline__ float interp(const V &v, f3 pos) {
-    const Taps t = locate(v, pos);
+__device__ __forceinline__ float interp_taps(const V &v, const Taps &t) {
     const float fx = t.fr.x, fy = t.fr.y, fz = t.fr.z;
     const int p = imax(imin(t.lo[0], v.sx - 2), 0);
     const bool lf = t.lo[0] == p, uf = t.up[0] == p;
@@ -1417,6 +1416,9 @@ __device__ __forceinline__ float interp(const V &v, f3 pos) {
             + ((c0 * (1 - fx) + c1 * fx) * (1 - fy) + (d0 * (1 - fx) + d1 * fx) * fy) * fz)
            * kShort2Float;
 }
+
+template <class V>
+__device__ __forceinline__ float interp(const V &v, f3 pos) { return interp_taps(v, locate(v, pos)); }
 
 // Central differences blended trilinearly (commons.h:215-301).  For axis A the four planes are
 // ll = max(base-1,0), lo = max(base,0), up = min(base+1,size-1), uu = min(base+2,size-1); the low
@@ -1514,7 +1516,8 @@ constexpr short kSkipShort = kSkipShortFwd;
 struct SkipGrid {
     const unsigned char *flags;   // nullptr = no skipping
     int nbx, nby, nbz;
-    float kx, ky, kz;             // size / dim per axis
+    float kx, ky, kz;             // size / dim per axis, divided by 8 (voxels -> bricks)
+    float bx_max, by_max, bz_max; // last brick index per axis, as floats
     int two_phase;                // loop shape (only with flags)
     unsigned long long *trace;    // debugging (KFH_RAY_TRACE): per wave {start, end} of the 100 MHz wall clock, else nullptr
     const unsigned *order;        // launch slot -> screen tile (most expensive tiles of the last frame first), or nullptr
@@ -1527,11 +1530,18 @@ struct SkipGrid {
 };
 
 template <class V>
-__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const V &v, f3 pos) {
-    const int vx = (int)floorf(pos.x * g.kx - 0.5f), vy = (int)floorf(pos.y * g.ky - 0.5f), vz = (int)floorf(pos.z * g.kz - 0.5f);
-    const int bx = imin(imax(vx, 0), v.sx - 1) >> 3, by = imin(imax(vy, 0), v.sy - 1) >> 3, bz = imin(imax(vz, 0), v.sz - 1) >> 3;
-    return g.flags[bx + g.nbx * (by + g.nby * bz)] == 0;
+__device__ __forceinline__ unsigned char brick_flag(const SkipGrid &g, const V &v, f3 pos) {
+    // brick of the base voxel: floor((pos * size/dim - 0.5) / 8), clamped to the grid - as three instructions per axis
+    // (fused multiply-add, median-of-three clamp in float, truncation: the clamped value is >= 0).  The base voxel is
+    // only located to within one voxel here, which is what the dilation of the flags allows for.
+    const unsigned bx = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.x, g.kx, -0.0625f), 0.f, g.bx_max);
+    const unsigned by = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.y, g.ky, -0.0625f), 0.f, g.by_max);
+    const unsigned bz = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.z, g.kz, -0.0625f), 0.f, g.bz_max);
+    (void)v;
+    return g.flags[__umul24(__umul24(bz, (unsigned)g.nby) + by, (unsigned)g.nbx) + bx];
 }
+template <class V>
+__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const V &v, f3 pos) { return brick_flag(g, v, pos) == 0; }
 
 __device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z) {
     const int x0 = x >= 2 ? (x - 2) >> 3 : 0, x1 = imin((x + 1) >> 3, nbx - 1);
@@ -1628,6 +1638,20 @@ __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b
 // the reference loop would do something other than "continue" (leave the volume, cross zero, or switch from the large to
 // the small step, cpp:709-716) decides the ray's next state.  Samples past that lane are discarded.  The chain per ray
 // shrinks Q-fold and the frame exposes Q times more waves; decisions and bits are those of the serial loop.
+// value of the group's first / last lane: for four lanes per ray a quad permute of the data path (DPP), no LDS round trip
+template <int Q>
+__device__ __forceinline__ int group_first(int x, int base) {
+    if constexpr (Q == 4) return __builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true);
+    else return __shfl(x, base, 64);
+}
+template <int Q>
+__device__ __forceinline__ int group_last(int x, int base) {
+    if constexpr (Q == 4) return __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    else return __shfl(x, base + Q - 1, 64);
+}
+template <int Q> __device__ __forceinline__ float group_first(float x, int base) { return __builtin_bit_cast(float, group_first<Q>(__builtin_bit_cast(int, x), base)); }
+template <int Q> __device__ __forceinline__ float group_last(float x, int base) { return __builtin_bit_cast(float, group_last<Q>(__builtin_bit_cast(int, x), base)); }
+
 template <int Q, class V>
 __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg, unsigned px, unsigned py,
                                                  const M4 &view, float nearPlane, float farPlane, float step,
@@ -1675,15 +1699,15 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
         if (first) {
             // cpp:706-708: the march only starts if the sample at tnear (lane 0 of this round) is positive
             first = false;
-            const float f0 = __shfl(f, base, 64);
-            const int lazy0 = __shfl((int)s_lazy, base, 64);
-            const int in0 = __shfl((int)in_range, base, 64);
+            const float f0 = group_first<Q>(f, base);
+            const int lazy0 = group_first<Q>((int)s_lazy, base);
+            const int in0 = group_first<Q>((int)in_range, base);
             if (in0 && !lazy0 && !(f0 > 0)) return miss;
         }
         if (evmask == 0) {   // all Q samples are plain "continue": f_t <- last of them, t <- its time + stepsize
-            f_t = __shfl(f, base + Q - 1, 64);
-            lazy = __shfl((int)s_lazy, base + Q - 1, 64) != 0;
-            t_ft = __shfl(tq, base + Q - 1, 64);
+            f_t = group_last<Q>(f, base);
+            lazy = group_last<Q>((int)s_lazy, base) != 0;
+            t_ft = group_last<Q>(tq, base);
             t = t_ft + stepsize;
             continue;
         }
@@ -2139,7 +2163,8 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     SkipGrid g;
     g.flags = flags;
     g.nbx = (sx + 7) >> 3; g.nby = (sy + 7) >> 3; g.nbz = (sz + 7) >> 3;
-    g.kx = sx / dim.x; g.ky = sy / dim.y; g.kz = sz / dim.z;
+    g.kx = sx / dim.x * 0.125f; g.ky = sy / dim.y * 0.125f; g.kz = sz / dim.z * 0.125f;
+    g.bx_max = (float)((sx - 1) >> 3); g.by_max = (float)((sy - 1) >> 3); g.bz_max = (float)((sz - 1) >> 3);
     static const long tp = env_long("KFH_RAY_TWO_PHASE", 0, 1, 0);
     g.two_phase = (flags && tp) ? 1 : 0;
     g.trace = nullptr;
