@@ -1351,7 +1351,9 @@ struct VolViewT {
 // instead of two 64-bit multiply-adds).
 template <class V>
 __device__ __forceinline__ unsigned voxel_byte_offset(const V &v, int x, int y, int z) {
-    return ((unsigned)x + (unsigned)y * (unsigned)v.sx + (unsigned)z * (unsigned)v.plane) * 4u;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction): coordinates, sx and the plane size
+    // sx*sy are below 2^24 for every volume the context accepts (<= 1024^3), the products below 2^30
+    return ((unsigned)x + __umul24((unsigned)y, (unsigned)v.sx) + __umul24((unsigned)z, (unsigned)v.plane)) * 4u;
 }
 
 template <class V>

@@ -503,6 +503,10 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
         g_last_error = "kfh_create: volume must hold between 2 and 2^30 voxels (32-bit voxel addressing in the ray march)";
         return nullptr;
     }
+    if ((unsigned long long)res[0] * res[1] >= (1ull << 24)) {
+        g_last_error = "kfh_create: an x-y plane of the volume must hold fewer than 2^24 voxels (24-bit multiplies in the voxel addressing)";
+        return nullptr;
+    }
     if (device >= 0 && !HIP_TRY(hipSetDevice(device))) return nullptr;
     kfh_context *c = new kfh_context();
     HIP_TRY(hipGetDevice(&c->device));

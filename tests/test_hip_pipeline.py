@@ -147,9 +147,10 @@ def test_sensor_dropout_and_saturated_frames(hip, kfmod, orc):
 
 def test_create_rejects_what_it_cannot_serve(hip, kfmod):
     """Creation fails loudly (no context, a message) instead of mis-addressing: more than 2^30 voxels (the ray march uses
-    32-bit voxel byte offsets), an empty image, no pyramid level or more than KFH_MAX_LEVELS."""
+    32-bit voxel byte offsets), an x-y plane of 2^24 voxels or more (24-bit multiplies), an empty image, no pyramid level or more than KFH_MAX_LEVELS."""
     s = util.small_stream(1)
     for args, what in ((((64, 48), (1024, 1024, 1025), util.VOL_DIM, s.init_pos), "2^30"),
+                       (((64, 48), (4096, 4096, 8), util.VOL_DIM, s.init_pos), "2^24"),
                        (((0, 48), (16, 16, 16), util.VOL_DIM, s.init_pos), "bad argument"),
                        (((64, 48), (16, 16, 16), util.VOL_DIM, s.init_pos, ()), "bad argument"),
                        (((64, 48), (16, 16, 16), util.VOL_DIM, s.init_pos, (1,) * 9), "bad argument")):
