@@ -195,6 +195,8 @@ def main():
     updated = kf.integrate_updated()
     icp_iters = kf.icp_iterations()
     icp_by_level = kf.icp_level_iterations()
+    if kf.barrier_timeouts():
+        raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
     fallbacks = kf.solve_fallbacks()
     poses, tracked, integrated = kf.frame_log(n_frames)
     kf.close()

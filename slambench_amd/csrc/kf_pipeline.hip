@@ -63,6 +63,7 @@ struct kfh_context {
     float *alt_floatDepth = nullptr;
     std::vector<float *> alt_scaled;
     std::vector<float4 *> alt_inV, alt_inN;
+    unsigned seen_barrier_timeouts = 0;
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
@@ -172,6 +173,12 @@ static void refresh_mirror(kfh_context *c) {
     HIP_TRY(hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->mirror_stale = false;
+    if (c->h_state->barrier_timeouts > c->seen_barrier_timeouts) {    // k_icp_tail gave up waiting: say so, loudly
+        fprintf(stderr, "kfusion-hip: %u workgroup(s) timed out at the ICP grid barrier (device oversubscribed?); the poses of "
+                        "the affected frames are not to be trusted\n", c->h_state->barrier_timeouts - c->seen_barrier_timeouts);
+        g_last_error = "ICP grid barrier timed out";
+        c->seen_barrier_timeouts = c->h_state->barrier_timeouts;
+    }
 }
 
 static void flush_pending(kfh_context *c) {
