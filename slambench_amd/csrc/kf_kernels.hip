@@ -545,7 +545,8 @@ __device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float i
     pose = matmul(delta, pose);
     double n2 = 0.0;
     for (int i = 0; i < 6; ++i) n2 += x[i] * x[i];
-    return sqrt(n2) < icp_threshold;
+    // norm(x) < icp_threshold (cpp:772), compared as squares: no square root on this serial path
+    return icp_threshold > 0.f && n2 < (double)icp_threshold * (double)icp_threshold;
 }
 
 __global__ __launch_bounds__(1024) void k_solve(DevState *__restrict__ st, float *__restrict__ out32,
@@ -715,6 +716,19 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
                                             unsigned prev_nblocks, float icp_threshold, bool writer,
                                             unsigned long long *trace = nullptr) {
     ICP_STAMP(0);
+    // the partial rows of the previous launch are requested before the state record that says whether they are needed
+    // (one round trip instead of two on the path of every executed iteration; a skipped one discards them)
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    constexpr int G = ICP_THREADS / 32;
+    constexpr int PRE = 8;                        // rows per thread fetched ahead: covers 256 blocks
+    float pre[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const unsigned b = (unsigned)g + (unsigned)k * G;
+        pre[k] = 0.f;
+        if (it > 0 && b < prev_nblocks)
+            pre[k] = COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
+    }
     if (threadIdx.x == 0) {
         if (it == 0) {
             sh.pose = st->pose;
@@ -739,10 +753,11 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     __syncthreads();
     ICP_STAMP(1);
     if (!sh.prev_executed) return;   // uniform: the previous iteration was skipped, nothing to solve
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    constexpr int G = ICP_THREADS / 32;
     float acc = 0.f;
-    for (unsigned b = g; b < prev_nblocks; b += G)
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+        if ((unsigned)g + (unsigned)k * G < prev_nblocks) acc += pre[k];
+    for (unsigned b = (unsigned)g + PRE * G; b < prev_nblocks; b += G)     // (more than 256 blocks: KFH_ICP_BLOCKS)
         acc += COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
     sh.sm[g][c] = acc;
     __syncthreads();
@@ -761,10 +776,10 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
         const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast, sh.jacobi_ws);   // < 0: timing probe
         sh.pose = pose;
         if (converged) sh.done[prev_level] = 1;
-        if (writer) {
-            st->icp_iterations += 1;
-            st->icp_level_iterations[prev_level] += 1;
-            if (!fast) st->solve_fallbacks += 1;
+        if (writer) {   // counters: atomics without a return value, so that this thread does not wait for the round trips
+            atomicAdd(&st->icp_iterations, 1ull);
+            atomicAdd(&st->icp_level_iterations[prev_level], 1ull);
+            if (!fast) atomicAdd(&st->solve_fallbacks, 1ull);
         }
     }
     ICP_STAMP(3);
