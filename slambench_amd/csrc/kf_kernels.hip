@@ -710,7 +710,10 @@ struct IcpShared {
 #define ICP_STAMP(i) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[i] = __builtin_readcyclecounter(); } while (0)
 // COHERENT: the state record and the partial sums were written by other workgroups of THIS launch (k_icp_tail, after its
 // grid barrier), so they are read with agent-scope atomic loads, which no cache of this CU or XCD may serve stale.
-template <bool COHERENT = false>
+// AHEAD: request the partial rows before the state record (right for launches whose previous iteration usually ran; a
+// launch that usually finds it skipped - the tail, the closing launch - would only put a useless round trip in front of
+// its own later loads, which return in order).
+template <bool COHERENT = false, bool AHEAD = true>
 __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict__ st, const IcpState *iters,
                                             const float *partials_prev, int it, int prev_level,
                                             unsigned prev_nblocks, float icp_threshold, bool writer,
@@ -726,7 +729,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     for (int k = 0; k < PRE; ++k) {
         const unsigned b = (unsigned)g + (unsigned)k * G;
         pre[k] = 0.f;
-        if (it > 0 && b < prev_nblocks)
+        if (AHEAD && it > 0 && b < prev_nblocks)
             pre[k] = COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
     }
     if (threadIdx.x == 0) {
@@ -756,8 +759,8 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < PRE; ++k)
-        if ((unsigned)g + (unsigned)k * G < prev_nblocks) acc += pre[k];
-    for (unsigned b = (unsigned)g + PRE * G; b < prev_nblocks; b += G)     // (more than 256 blocks: KFH_ICP_BLOCKS)
+        if (AHEAD && (unsigned)g + (unsigned)k * G < prev_nblocks) acc += pre[k];
+    for (unsigned b = (unsigned)g + (AHEAD ? PRE * G : 0); b < prev_nblocks; b += G)     // (not AHEAD, or more than 256 blocks: KFH_ICP_BLOCKS)
         acc += COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
     sh.sm[g][c] = acc;
     __syncthreads();
@@ -898,11 +901,11 @@ struct IcpIterArgs {
 };
 
 // state entering iteration `it` (solve of iteration it-1 included), recorded by the writer block; true if `it` is to run
-template <bool COHERENT = false>
+template <bool COHERENT = false, bool AHEAD = true>
 __device__ __forceinline__ bool icp_enter(IcpShared &sh, const IcpIterArgs &a, int it, const float *partials_prev, bool writer) {
     DevState *__restrict__ st = a.st;
     unsigned long long *trace = a.trace;
-    icp_advance<COHERENT>(sh, st, a.iters, partials_prev, it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer, trace);
+    icp_advance<COHERENT, AHEAD>(sh, st, a.iters, partials_prev, it, a.prev_level, a.prev_nblocks, a.icp_threshold, writer, trace);
     if (threadIdx.x == 0) {
         sh.executed = sh.done[a.level] ? 0 : 1;
         if (writer) {
@@ -1015,10 +1018,10 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
         if (j == t.n_its) {
             // every queued iteration ran (rare): the update of the last one, as k_icp_final would apply it
             if (!(closes && writer)) return;
-            icp_advance<true>(sh, a.st, a.iters, prev, it, a.level, a.nblocks, a.icp_threshold, true);
+            icp_advance<true, true>(sh, a.st, a.iters, prev, it, a.level, a.nblocks, a.icp_threshold, true);
             break;
         }
-        const bool run = j == 0 ? icp_enter<false>(sh, a, it, prev, writer) : icp_enter<true>(sh, a, it, prev, writer);
+        const bool run = j == 0 ? icp_enter<false, false>(sh, a, it, prev, writer) : icp_enter<true, true>(sh, a, it, prev, writer);
         if (!run) {
             // the level is done: the remaining iterations would only hand the state on (as their launches did)
             if (!writer) return;
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
                                                           int prev_level, unsigned prev_nblocks, float icp_threshold,
                                                           int ops, ControlArgs a) {
     __shared__ IcpShared sh;
-    icp_advance(sh, st, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, true);
+    icp_advance<false, false>(sh, st, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, true);
     close_icp_loop(sh, st, log, ops, a);
 }
 
