@@ -725,13 +725,16 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     constexpr int G = ICP_THREADS / 32;
     constexpr int PRE = 8;                        // rows per thread fetched ahead: covers 256 blocks
     float pre[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const unsigned b = (unsigned)g + (unsigned)k * G;
-        pre[k] = 0.f;
-        if (AHEAD && it > 0 && b < prev_nblocks)
-            pre[k] = COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
+    // all PRE loads of a thread are issued back to back (one round trip, not PRE)
+#define KFH_FETCH_ROWS()                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < PRE; ++k) {                                                                            \
+        const unsigned b = (unsigned)g + (unsigned)k * G;                                                                        \
+        pre[k] = 0.f;                                                                                                            \
+        if (it > 0 && b < prev_nblocks)                                                                                          \
+            pre[k] = COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) \
+                              : partials_prev[(size_t)b * 32 + c];                                                               \
     }
+    if (AHEAD) { KFH_FETCH_ROWS() }
     if (threadIdx.x == 0) {
         if (it == 0) {
             sh.pose = st->pose;
@@ -756,11 +759,13 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     __syncthreads();
     ICP_STAMP(1);
     if (!sh.prev_executed) return;   // uniform: the previous iteration was skipped, nothing to solve
+    if (!AHEAD) { KFH_FETCH_ROWS() }
+#undef KFH_FETCH_ROWS
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < PRE; ++k)
-        if (AHEAD && (unsigned)g + (unsigned)k * G < prev_nblocks) acc += pre[k];
-    for (unsigned b = (unsigned)g + (AHEAD ? PRE * G : 0); b < prev_nblocks; b += G)     // (not AHEAD, or more than 256 blocks: KFH_ICP_BLOCKS)
+        if ((unsigned)g + (unsigned)k * G < prev_nblocks) acc += pre[k];
+    for (unsigned b = (unsigned)g + PRE * G; b < prev_nblocks; b += G)     // (more than 256 blocks: KFH_ICP_BLOCKS)
         acc += COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
     sh.sm[g][c] = acc;
     __syncthreads();
