@@ -1762,6 +1762,11 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
 
 // Pixel mapping shared by raycast and renderVolume.  A wave marches 64/Q rays laid out as a small screen tile (8x8, 8x4,
 // 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a 256-thread block is 2x2 such tiles.
+#ifndef KFH_RAY_BLOCK_WAVES
+#define KFH_RAY_BLOCK_WAVES 4      // waves per ray-march workgroup: 4 (2x2 wave tiles), 2 (2x1) or 1
+#endif
+constexpr int RAY_WX = KFH_RAY_BLOCK_WAVES >= 2 ? 2 : 1, RAY_WY = KFH_RAY_BLOCK_WAVES / RAY_WX;
+constexpr int RAY_BLOCK = 64 * KFH_RAY_BLOCK_WAVES;
 template <int Q>
 __device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y, unsigned bx, unsigned by) {
     constexpr int R = 64 / Q;                         // rays per wave
@@ -1769,8 +1774,8 @@ __device__ __forceinline__ void tile_pixel(unsigned &x, unsigned &y, unsigned bx
     constexpr int RH = R / RW;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned r = lane / Q;
-    x = (bx * 2 + (wave & 1)) * RW + (r % RW);
-    y = (by * 2 + (wave >> 1)) * RH + (r / RW);
+    x = (bx * RAY_WX + (wave % RAY_WX)) * RW + (r % RW);
+    y = (by * RAY_WY + (wave / RAY_WX)) * RH + (r / RW);
 }
 
 template <int Q, class V>
@@ -1782,7 +1787,7 @@ __device__ __forceinline__ float4 march(const V &v, const SkipGrid &sg, unsigned
 
 // raycastKernel (cpp:726-757)
 template <int Q, int FD>
-__global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal, unsigned W,
+__global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal, unsigned W,
                                                  unsigned H, const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                  unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
                                                  float farPlane, float step, float largestep, SkipGrid sg, f3 rdim) {
@@ -1817,7 +1822,7 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
             atomicMax(sg.cost + nx + ny * (int)gridDim.x, (unsigned)work);
     }
     if (sg.trace && (threadIdx.x & 63) == 0) {
-        const unsigned wave = slot * 4 + (threadIdx.x >> 6);
+        const unsigned wave = slot * KFH_RAY_BLOCK_WAVES + (threadIdx.x >> 6);
         sg.trace[4 * wave] = t_start;
         sg.trace[4 * wave + 1] = wall_clock64();
         sg.trace[4 * wave + 2] = (unsigned long long)work;
@@ -1844,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
 
 // renderVolumeKernel (cpp:880-913)
 template <int Q, int FD>
-__global__ __launch_bounds__(256) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
+__global__ __launch_bounds__(RAY_BLOCK) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
                                                        const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                        unsigned sz, f3 dim, const RayParams *__restrict__ rp,
                                                        float nearPlane, float farPlane, float step, float largestep,
@@ -2246,7 +2251,7 @@ static int ray_group() {   // lanes per ray (KFH_RAY_GROUP = 1, 2, 4, 8)
 }
 static dim3 ray_grid(int q, unsigned W, unsigned H) {
     const unsigned rw = (q <= 2) ? 8 : 4, rh = (64 / q) / rw;
-    return dim3((W + 2 * rw - 1) / (2 * rw), (H + 2 * rh - 1) / (2 * rh));
+    return dim3((W + RAY_WX * rw - 1) / (RAY_WX * rw), (H + RAY_WY * rh - 1) / (RAY_WY * rh));
 }
 
 static long env_long(const char *name, long lo, long hi, long dflt) {
@@ -2308,21 +2313,21 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
     if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
     static WaveTrace wt("KFH_RAY_TRACE");
     const dim3 tg = ray_grid(ray_group(), W, H);
-    sg.trace = wt.arm((size_t)tg.x * tg.y * 4, s);
+    sg.trace = wt.arm((size_t)tg.x * tg.y * KFH_RAY_BLOCK_WAVES, s);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group()) {
-        case 1: k_raycast<1, 1><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 1><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 1><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 1><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
         }
     } else {
         switch (ray_group()) {
-        case 1: k_raycast<1, 0><<<ray_grid(1, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 0><<<ray_grid(2, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 0><<<ray_grid(8, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 0><<<ray_grid(4, W, H), 256, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
         }
     }
     wt.dump();
@@ -2361,17 +2366,17 @@ void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsi
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group()) {
-        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        default: k_render_volume<4, 1><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
         }
     } else {
         switch (ray_group()) {
-        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        default: k_render_volume<4, 0><<<ray_grid(4, W, H), 256, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        default: k_render_volume<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
         }
     }
 }
