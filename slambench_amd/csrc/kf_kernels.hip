@@ -1546,6 +1546,7 @@ struct SkipGrid {
     int two_phase;                // loop shape (only with flags)
     unsigned long long *trace;    // debugging (KFH_RAY_TRACE): per wave {start, end} of the 100 MHz wall clock, else nullptr
     const unsigned *order;        // launch slot -> screen tile (most expensive tiles of the last frame first), or nullptr
+    unsigned tiles_x, tiles_y;    // the tile grid of the dispatch order: tiles of 2x2 wave tiles, whatever the workgroup size
     unsigned *cost;               // per screen tile: march rounds of its longest ray, for the next frame's order
     // the NEXT queued frame's OP_TRACK_BEGIN (scalar glue, ~3 us as a launch of its own), done by one thread of the last -
     // cheapest - slot while the rest of the launch marches; nothing in this launch reads what it writes
@@ -1763,7 +1764,7 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
 // Pixel mapping shared by raycast and renderVolume.  A wave marches 64/Q rays laid out as a small screen tile (8x8, 8x4,
 // 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a 256-thread block is 2x2 such tiles.
 #ifndef KFH_RAY_BLOCK_WAVES
-#define KFH_RAY_BLOCK_WAVES 4      // waves per ray-march workgroup: 4 (2x2 wave tiles), 2 (2x1) or 1
+#define KFH_RAY_BLOCK_WAVES 2      // waves per ray-march workgroup: 4 (2x2 wave tiles), 2 (2x1) or 1; 2 packs the CUs best (profiles/r01_sweeps.md)
 #endif
 constexpr int RAY_WX = KFH_RAY_BLOCK_WAVES >= 2 ? 2 : 1, RAY_WY = KFH_RAY_BLOCK_WAVES / RAY_WX;
 constexpr int RAY_BLOCK = 64 * KFH_RAY_BLOCK_WAVES;
@@ -1801,9 +1802,20 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
     const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x;
     if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
         track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
-    const unsigned tile = sg.order ? sg.order[slot] : slot;
+    // A dispatch tile is 2x2 wave tiles.  With workgroups smaller than that (KFH_RAY_BLOCK_WAVES < 4, which pack the CUs
+    // better) a tile is PARTS workgroups whose slots are 8 apart, i.e. on the same XCD: slot = 8 * PARTS * j + 8 * part + class.
+    constexpr unsigned PARTS = 4 / KFH_RAY_BLOCK_WAVES;
+    const unsigned tslot = PARTS == 1 ? slot : (slot / (8 * PARTS)) * 8 + (slot % 8);
+    const unsigned part = PARTS == 1 ? 0u : (slot / 8) % PARTS;
+    if (tslot >= sg.tiles_x * sg.tiles_y) return;      // (padding of the launch to a multiple of 8 * PARTS slots)
+    const unsigned tile = sg.order ? sg.order[tslot] : tslot;
     unsigned x, y;
-    tile_pixel<Q>(x, y, tile % gridDim.x, tile / gridDim.x);
+    {
+        const unsigned tx = tile % sg.tiles_x, ty = tile / sg.tiles_x;
+        // workgroup inside the tile: RAY_WX x RAY_WY wave tiles each, (2 / RAY_WX) x (2 / RAY_WY) of them
+        const unsigned px_ = part % (2 / RAY_WX), py_ = part / (2 / RAY_WX);
+        tile_pixel<Q>(x, y, tx * (2 / RAY_WX) + px_, ty * (2 / RAY_WY) + py_);
+    }
     if (x >= W || y >= H) return;     // uniform per ray group: all Q lanes share the pixel
     const M4 view = rp->view;
     VolViewT<FD> v;
@@ -1817,9 +1829,9 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
         // number per tile: a silhouette ray that just misses an object marches four times longer than its neighbour that
         // hits it, and which tile holds it changes with every camera step
         const int lane = (int)(threadIdx.x & 63u);
-        const int nx = (int)(tile % gridDim.x) + lane % 3 - 1, ny = (int)(tile / gridDim.x) + lane / 3 - 1;
-        if (sg.cost && lane < 9 && nx >= 0 && ny >= 0 && nx < (int)gridDim.x && ny < (int)gridDim.y)
-            atomicMax(sg.cost + nx + ny * (int)gridDim.x, (unsigned)work);
+        const int nx = (int)(tile % sg.tiles_x) + lane % 3 - 1, ny = (int)(tile / sg.tiles_x) + lane / 3 - 1;
+        if (sg.cost && lane < 9 && nx >= 0 && ny >= 0 && nx < (int)sg.tiles_x && ny < (int)sg.tiles_y)
+            atomicMax(sg.cost + nx + ny * (int)sg.tiles_x, (unsigned)work);
     }
     if (sg.trace && (threadIdx.x & 63) == 0) {
         const unsigned wave = slot * KFH_RAY_BLOCK_WAVES + (threadIdx.x >> 6);
@@ -2199,6 +2211,7 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     g.two_phase = (flags && tp) ? 1 : 0;
     g.trace = nullptr;
     g.order = nullptr; g.cost = nullptr;
+    g.tiles_x = 0; g.tiles_y = 0;
     g.next_state = nullptr; g.next_frame = 0; g.next_tracking_rate = 1;
     for (int i = 0; i < 4; ++i) g.next_k[i] = 0.f;
     return g;
@@ -2254,6 +2267,18 @@ static dim3 ray_grid(int q, unsigned W, unsigned H) {
     return dim3((W + RAY_WX * rw - 1) / (RAY_WX * rw), (H + RAY_WY * rh - 1) / (RAY_WY * rh));
 }
 
+// dispatch tiles: 2x2 wave tiles (the workgroup of KFH_RAY_BLOCK_WAVES = 4), whatever the workgroup size
+static dim3 ray_tile_dim(int q, unsigned W, unsigned H) {
+    const unsigned rw = (q <= 2) ? 8 : 4, rh = (64 / q) / rw;
+    return dim3((W + 2 * rw - 1) / (2 * rw), (H + 2 * rh - 1) / (2 * rh));
+}
+// launch grid of k_raycast: one workgroup per part of a tile, slots padded to whole rounds of 8 * parts
+static dim3 raycast_launch_grid(int q, unsigned W, unsigned H) {
+    const dim3 t = ray_tile_dim(q, W, H);
+    const unsigned parts = 4 / KFH_RAY_BLOCK_WAVES, n = t.x * t.y;
+    if (parts == 1) return t;
+    return dim3(((n + 7) / 8) * 8 * parts, 1);
+}
 static long env_long(const char *name, long lo, long hi, long dflt) {
     const char *e = getenv(name);
     if (!e) return dflt;
@@ -2312,35 +2337,36 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
     }
     if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
     static WaveTrace wt("KFH_RAY_TRACE");
-    const dim3 tg = ray_grid(ray_group(), W, H);
+    const dim3 tg = raycast_launch_grid(ray_group(), W, H), td = ray_tile_dim(ray_group(), W, H);
+    sg.tiles_x = td.x; sg.tiles_y = td.y;
     sg.trace = wt.arm((size_t)tg.x * tg.y * KFH_RAY_BLOCK_WAVES, s);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group()) {
-        case 1: k_raycast<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 1><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 1><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 1><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 1><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
         }
     } else {
         switch (ray_group()) {
-        case 1: k_raycast<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 0><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 2: k_raycast<2, 0><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 8: k_raycast<8, 0><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        default: k_raycast<4, 0><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
         }
     }
     wt.dump();
 }
 
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
-    const dim3 tg = ray_grid(ray_group(), W, H);
+    const dim3 tg = ray_tile_dim(ray_group(), W, H);
     k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y, 0u);
 }
-void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_grid(ray_group(), W, H); *tx = g.x; *ty = g.y; }
+void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_tile_dim(ray_group(), W, H); *tx = g.x; *ty = g.y; }
 bool ray_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_RAY_REORDER"); return !(e && e[0] == '0'); }(); return on; }
 
-unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_grid(ray_group(), W, H); return g.x * g.y; }
+unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_tile_dim(ray_group(), W, H); return g.x * g.y; }
 
 __global__ void k_iota(unsigned *p, unsigned n) {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
