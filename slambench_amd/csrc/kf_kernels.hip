@@ -1762,7 +1762,7 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
 }
 
 // Pixel mapping shared by raycast and renderVolume.  A wave marches 64/Q rays laid out as a small screen tile (8x8, 8x4,
-// 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a 256-thread block is 2x2 such tiles.
+// 4x4, 4x2 for Q = 1, 2, 4, 8), the Q lanes of a ray being adjacent; a workgroup is KFH_RAY_BLOCK_WAVES of them (2x1 by default), a dispatch tile 2x2.
 #ifndef KFH_RAY_BLOCK_WAVES
 #define KFH_RAY_BLOCK_WAVES 2      // waves per ray-march workgroup: 4 (2x2 wave tiles), 2 (2x1) or 1; 2 packs the CUs best (profiles/r01_sweeps.md)
 #endif
