@@ -6,8 +6,21 @@
 #ifndef KFUSION_HIP_COMMONS_H_
 #define KFUSION_HIP_COMMONS_H_
 
+// the standard headers the reference's commons.h:21-31 hands to whoever includes <kernels.h> (benchmark.cpp relies on
+// <fstream>, <iostream>, <iomanip> and uint16_t arriving this way)
+#include <limits.h>
+#include <stdint.h>
 #include <sys/stat.h>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <iterator>
 #include <string>
+#include <vector>
 
 typedef unsigned int uint;
 typedef unsigned short ushort;
@@ -25,7 +38,7 @@ static inline uint3 make_uint3(unsigned int x, unsigned int y, unsigned int z) {
 static inline float3 make_float3(float x, float y, float z) { float3 v = {x, y, z}; return v; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 v = {x, y, z, w}; return v; }
 static inline float3 operator*(const float3 &a, const float3 &b) { return make_float3(a.x * b.x, a.y * b.y, a.z * b.z); }
-static inline float4 operator/(const float4 &a, float b) { return make_float4(a.x / b, a.y / b, a.z / b, a.w / b); }
+static inline float4 operator/(const float4 &a, float b) { return make_float4(a.x / b, a.y / b, a.z / b, a.w / b); }   // cutil_math.h: float4 / float (an int ratio converts)
 
 // commons.h:52-57
 static inline bool is_file(const std::string &path) {
@@ -33,5 +46,8 @@ static inline bool is_file(const std::string &path) {
     if (stat(path.c_str(), &buf) != 0) return false;
     return S_ISREG(buf.st_mode);
 }
+
+// commons.h:34 — the reference's commons.h pulls in the run-time parameters (struct Configuration); drivers get them through <kernels.h>
+#include "default_parameters.h"
 
 #endif

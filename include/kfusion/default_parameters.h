@@ -11,6 +11,8 @@
 #include <sys/stat.h>
 
 #include <cstdlib>
+#include <ctime>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -49,6 +51,8 @@ struct Configuration {
     float3 volume_size, initial_pos_factor;
     std::vector<int> pyramid;
     std::string dump_volume_file, input_file, log_file;
+    std::ofstream log_filestream;      // default_parameters.h:92-93: the GUI mains open the log themselves
+    std::ostream *log_stream;
     float4 camera;
     bool camera_overrided;
     float mu;
@@ -99,11 +103,33 @@ struct Configuration {
                   << "-z  (--rendering-rate)   : default is " << default_rendering_rate << std::endl;
     }
 
+    // report header of the GUI mains' log (default_parameters.h:124-154); the first line carries the wall clock
+    void print_values(std::ostream &out) {
+        char stamp[80];
+        const time_t now = time(NULL);
+        strftime(stamp, sizeof(stamp), "%Y-%m-%d %I:%M:%S", localtime(&now));
+        out << "SLAMBench Report run started:\t" << stamp << "\n\n"
+            << "Scene properties:\n=================\n\n"
+            << "input-file: " << input_file << "\n"
+            << "volume-size: " << volume_size.x << "," << volume_size.y << "," << volume_size.z << "\n"
+            << "camera: " << camera.x << "," << camera.y << "," << camera.z << "," << camera.w << "\n"
+            << "init-pose: " << initial_pos_factor.x << "," << initial_pos_factor.y << "," << initial_pos_factor.z << "\n\n"
+            << "Algorithmic properties:\n=======================\n\n"
+            << "compute-size-ratio: " << compute_size_ratio << "\n"
+            << "volume-resolution: " << volume_resolution.x << "," << volume_resolution.y << "," << volume_resolution.z << "    \n"
+            << "mu: " << mu << "\n"
+            << "icp-threshold: " << icp_threshold << "\n"
+            << "pyramid-levels: ";
+        for (size_t i = 0; i < pyramid.size(); ++i) out << (i ? "," : "") << pyramid[i];
+        out << "\ntracking-rate: " << tracking_rate << "\nintegration-rate: " << integration_rate << "\nrendering-rate: " << rendering_rate
+            << "\nfps: " << fps << std::endl;
+    }
+
     Configuration(unsigned int argc, char **argv)
         : compute_size_ratio(default_compute_size_ratio), integration_rate(default_integration_rate),
           rendering_rate(default_rendering_rate), tracking_rate(default_tracking_rate),
           volume_resolution(default_volume_resolution), volume_size(default_volume_size),
-          initial_pos_factor(default_initial_pos_factor), pyramid(default_iterations, default_iterations + 3),
+          initial_pos_factor(default_initial_pos_factor), pyramid(default_iterations, default_iterations + 3), log_stream(NULL),
           camera_overrided(false), mu(default_mu), fps(default_fps), blocking_read(default_blocking_read),
           icp_threshold(default_icp_threshold), no_gui(false), render_volume_fullsize(false) {
         camera = make_float4(0, 0, 0, 0);

@@ -63,12 +63,15 @@ protected:
 class RawDepthReader : public DepthReader {
     FILE *file_;
     uint2 size_;
+    unsigned int hdr_[2];   // header of the frame read last: the reference's reader keeps it in an uninitialised local, so at the
+                            // end of the file the stale value decides between "End of file." and "End of file(garbage found)."
     std::vector<unsigned short> scratch_;
 
 public:
     RawDepthReader(std::string filename, int fps, bool blocking_read) : file_(fopen(filename.c_str(), "rb")) {
         cameraOpen = cameraActive = false;
         size_ = make_uint2(0, 0);
+        hdr_[0] = hdr_[1] = 0;
         _frame = -1; _fps = fps; _blocking_read = blocking_read;
         unsigned int hdr[2];
         if (!file_ || fread(hdr, sizeof hdr, 1, file_) != 1) {
@@ -93,13 +96,13 @@ public:
         const size_t frame_bytes = 4 * sizeof(unsigned int) + pixels * sizeof(unsigned short) + pixels * 3;
         if (fseek(file_, (long)(frame_bytes * (size_t)_frame), SEEK_SET) != 0) return false;
         size_t got = 0, want = 0;
-        unsigned int hdr[2] = {0, 0};
-        got += fread(hdr, sizeof hdr, 1, file_);
+        unsigned int *hdr = hdr_;
+        got += fread(hdr, sizeof hdr_, 1, file_);
         const size_t n = (size_t)hdr[0] * hdr[1];
         want += 1 + n;
         if (depthMap) got += fread(depthMap, sizeof(unsigned short), n, file_);
         else { got += n; fseek(file_, (long)(n * sizeof(unsigned short)), SEEK_CUR); }
-        got += fread(hdr, sizeof hdr, 1, file_);
+        got += fread(hdr, sizeof hdr_, 1, file_);
         const size_t m = (size_t)hdr[0] * hdr[1];
         want += 1 + m;
         if (raw_rgb) got += fread(raw_rgb, 3, m, file_);

@@ -138,13 +138,12 @@ public:
     uint3 getModelResolution() { return volume_resolution_; }
     uint2 getComputationResolution() { return computation_size_; }
 
-    // not in the reference: lets synchroniseDevices() reach the stream of this instance
+    // not in the reference: the C-ABI handle behind this instance
     kfh_context *handle() { return ctx_; }
 };
 
-// kernels.h:197 — the reference's free function has no argument because its backends keep global state;
-// drivers that own one Kfusion register it once.
-inline kfh_context *&kfusion_sync_target() { static kfh_context *c = 0; return c; }
-inline void synchroniseDevices() { if (kfusion_sync_target()) kfh_synchronise(kfusion_sync_target()); }
+// kernels.h:197 — the reference's free function has no argument because its backends keep global state: here it waits
+// for every live Kfusion of the process (all queued work done, render targets filled)
+inline void synchroniseDevices() { kfh_synchronise_all(); }
 
 #endif

@@ -70,6 +70,8 @@ void kfh_destroy(kfh_context *ctx);
 void kfh_reset(kfh_context *ctx);
 /* synchroniseDevices()  kernels.h:197 */
 void kfh_synchronise(kfh_context *ctx);
+/* the same for every live context of the process: the reference's synchroniseDevices() takes no argument */
+void kfh_synchronise_all(void);
 
 /* ------------------------------------------------------------------ per-frame pipeline
  * bool Kfusion::preprocessing(const ushort* inputDepth, const uint2 inputSize)   cpp/kernels.cpp:915-922

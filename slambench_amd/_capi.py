@@ -29,6 +29,7 @@ SIGNATURES = {
     "kfh_destroy": (None, [vp]),
     "kfh_reset": (None, [vp]),
     "kfh_synchronise": (None, [vp]),
+    "kfh_synchronise_all": (None, []),
     "kfh_preprocessing": (i32, [vp, u16p, u, u]),
     "kfh_preprocessing_device": (i32, [vp, vp, u, u]),
     "kfh_tracking": (i32, [vp, fp, f, u, u]),

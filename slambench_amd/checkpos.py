@@ -81,6 +81,10 @@ def summarise(log_text: str, gt_text: str):
     errs = ate(log["traj"], gt)
     cols = dict(log["columns"])
     cols["ATE"] = errs
+    # ATE_wrt_kfusion leaves out the frames the reader dropped (their rows repeat the last valid position with valid = 0);
+    # it is reported only when frames were dropped (checkPos.py:99,127-128,147-148)
+    if log["dropped"] > 0:
+        cols["ATE_wrt_kfusion"] = [e for e, t in zip(errs, log["traj"]) if int(t[4]) == 1]
     report = {}
     for name in sorted(cols):
         if any(t in name for t in ("X", "Y", "Z", "frame", "tracked", "integrated")):

@@ -66,7 +66,6 @@ int main(int argc, char **argv) {
     init();
     {
         Kfusion kfusion(computationSize, config.volume_resolution, config.volume_size, init_pose, config.pyramid);
-        kfusion_sync_target() = kfusion.handle();
 
         double t[7];
         t[0] = tock();
@@ -99,7 +98,6 @@ int main(int argc, char **argv) {
             t[0] = tock();
         }
         if (config.dump_volume_file != "") kfusion.dumpVolume(config.dump_volume_file.c_str());
-        kfusion_sync_target() = 0;
     }
     clean();
     free(inputDepth);

@@ -113,6 +113,11 @@ struct kfh_context {
     M4 viewPose; bool useViewPose = false;
 };
 
+// every live context of the process: synchroniseDevices() of the reference (kernels.h:197) takes no argument because its
+// backends keep file-scope state, so kfh_synchronise_all() waits for all of them
+static std::mutex g_registry_mu;
+static std::vector<kfh_context *> g_registry;
+
 static hipEvent_t prof_event(kfh_context *c, int phase) {
     std::vector<hipEvent_t> &v = c->prof_events[phase];
     if (c->prof_used[phase] == v.size()) {
@@ -609,6 +614,10 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     if (getenv("KERNEL_TIMINGS")) { c->kernel_timings = true; c->prof_mask = (1u << KFH_PROF_COUNT) - 1u; }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        g_registry.push_back(c);
+    }
     return c;
 }
 
@@ -644,10 +653,15 @@ kfh_context *kfh_create_with_pose(uint32_t width, uint32_t height, const uint32_
 
 void kfh_destroy(kfh_context *c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        for (size_t i = 0; i < g_registry.size(); ++i)
+            if (g_registry[i] == c) { g_registry.erase(g_registry.begin() + i); break; }
+    }
     hipSetDevice(c->device);
     c->pend.valid = false;   // a frame still deferred is dropped with the context
     if (c->stream) hipStreamSynchronize(c->stream);
-    flush_pending(c);
+    c->pending.clear();      // render read-backs nobody synchronised for are dropped: the caller's buffers may be gone by now
     hipFree(c->d_input); hipFree(c->d_floatDepth);
     for (float *p : c->d_scaled) hipFree(p);
     for (float4 *p : c->d_inV) hipFree(p);
@@ -677,6 +691,21 @@ void kfh_synchronise(kfh_context *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->kernel_timings) prof_collect(c);
     flush_pending(c);
+}
+
+void kfh_synchronise_all(void) {
+    std::vector<kfh_context *> live;
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        live = g_registry;
+    }
+    int before = 0;
+    hipGetDevice(&before);
+    for (kfh_context *c : live) {
+        hipSetDevice(c->device);
+        kfh_synchronise(c);
+    }
+    if (!live.empty()) hipSetDevice(before);
 }
 
 int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) {
@@ -767,6 +796,13 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
 
 static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, uint32_t h) {
     const size_t bytes = (size_t)w * h * sizeof(uchar4);
+    // one staging buffer per render: an earlier image of the same kind still waiting for ANOTHER destination is delivered first
+    for (const PendingCopy &p : c->pending)
+        if (p.src == c->h_render[slot] && p.dst != out) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            flush_pending(c);
+            break;
+        }
     HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
     for (PendingCopy &p : c->pending) if (p.dst == out) { p.src = c->h_render[slot]; p.bytes = bytes; return; }
     PendingCopy p = {out, c->h_render[slot], bytes};

@@ -15,6 +15,7 @@ class RawDepthReader:
         if len(hdr) != 8:
             raise ValueError("Invalid Raw file.")
         self.width, self.height = struct.unpack("<II", hdr)
+        self.file_bytes = self.f.seek(0, 2)
         self.frame = -1
         self.frame_bytes = 16 + self.width * self.height * 2 + self.width * self.height * 3
 
@@ -35,10 +36,15 @@ class RawDepthReader:
         if len(hdr) != 8:
             return None
         w, h = struct.unpack("<II", hdr)
-        raw = self.f.read(w * h * 2)
-        if len(raw) != w * h * 2:
+        if w * h * 2 > self.file_bytes - self.f.tell():      # trailing garbage reads as a header: a short read ends the stream
             return None
+        raw = self.f.read(w * h * 2)
         return np.frombuffer(raw, dtype="<u2").reshape(h, w).copy()
+
+    def read_next_depth_frame_float(self):
+        """Metres as float32: ``(float) mm / 1000.0f`` (interface.h:299-307)."""
+        d = self.read_next_depth_frame()
+        return None if d is None else d.astype(np.float32) / np.float32(1000.0)
 
     def __iter__(self):
         while True:
@@ -75,6 +81,12 @@ class SceneDepthReader:
         return (481.20, 480.00, 319.50, 239.50)
 
     def read_next_depth_frame(self):
+        """uint16 millimetres: ``z * 1000.0f`` truncated (interface.h:139-149)."""
+        z = self.read_next_depth_frame_float()
+        return None if z is None else (z * np.float32(1000.0)).astype(np.uint16)
+
+    def read_next_depth_frame_float(self):
+        """z-depth in metres, float32 arithmetic throughout (interface.h:151-195)."""
         import os
         self.frame += 1
         path = os.path.join(self.dir, "scene_00_%04d.depth" % self.frame)
@@ -85,5 +97,4 @@ class SceneDepthReader:
         buf = np.zeros(self.WIDTH * self.HEIGHT, np.float32)
         n = min(vals.size, buf.size)
         buf[:n] = vals[:n]
-        z = buf.reshape(self.HEIGHT, self.WIDTH) / self.scale
-        return (z * np.float32(1000.0)).astype(np.uint16)
+        return buf.reshape(self.HEIGHT, self.WIDTH) / self.scale

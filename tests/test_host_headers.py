@@ -1,96 +1,117 @@
-"""Host side of the drop-in layer without a GPU: the C++ Configuration and depth readers of include/kfusion/ are
-compiled with g++ into a small probe and held against the reference's documented behaviour and the python twins."""
+"""Host side of the drop-in layer without a GPU, held to the REFERENCE's own compiled code.
+
+tests/golden/host_vectors.json is what the reference's `Configuration` (default_parameters.h:53-420), `RawDepthReader` /
+`SceneDepthReader` (interface.h:99-318) and `scene2raw` (thirdparty/scene2raw.cpp + lodepng.cpp) produced, compiled where they
+lie without stand-ins (oracle/Makefile target `ref`, tests/golden/make_host_vectors.py) on the seeded inputs of
+tests/golden/host_inputs.py.  Here the same probe source (tests/cpp/host_probe.cpp) is compiled against THIS repo's
+include/kfusion headers and the python twins are run on the same bytes: every output must be identical.
+"""
+import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from slambench_amd import checkkernels, rawio, scene2raw, synth
+from slambench_amd import checkkernels, rawio, scene2raw
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLDEN)
+import host_inputs  # noqa: E402
+import make_host_vectors as mk  # noqa: E402
+
+with open(os.path.join(GOLDEN, "host_vectors.json")) as _f:
+    VEC = json.load(_f)
+
+
+@pytest.fixture(scope="module")
+def work(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("host"))
+    host_inputs.make_inputs(d)
+    return d
 
 
 @pytest.fixture(scope="module")
 def probe(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("probe") / "host_side_probe")
-    subprocess.check_call(["g++", "-O1", "-std=gnu++11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_side_probe.cpp"), "-o", exe])
+    exe = str(tmp_path_factory.mktemp("probe") / "host_probe")
+    subprocess.check_call(["g++", "-O1", "-std=gnu++11", "-Wall", "-I", os.path.join(ROOT, "include", "kfusion"),
+                           os.path.join(ROOT, "tests", "cpp", "host_probe.cpp"), "-o", exe])
     return exe
 
 
-def run(probe, *args):
-    r = subprocess.run([probe] + list(args), capture_output=True, text=True, timeout=60)
-    last = [l for l in r.stdout.split("\n") if l.startswith("{")]
-    return r, (json.loads(last[-1]) if r.returncode == 0 and last else None)
+@pytest.mark.parametrize("case", VEC["config"], ids=lambda c: " ".join(c["args"]) or "defaults")
+def test_configuration_equals_the_reference_build(probe, work, case):
+    """Fields (float bits), print_values text, stderr chatter and exit code of every CLI case, error exits included."""
+    got = mk.run_config(probe, case["args"], work)
+    assert got["returncode"] == case["returncode"]
+    assert got["stdout"] == case["stdout"]
+    assert got["stderr"] == case["stderr"]
 
 
-def test_configuration_defaults_and_parsing(probe):
-    r, c = run(probe)
-    # default_parameters.h:25-43 (note -r defaults to 2 in code although the README says 1)
-    assert c["compute_size_ratio"] == 1 and c["integration_rate"] == 2 and c["rendering_rate"] == 4 and c["tracking_rate"] == 1
-    assert c["volume_resolution"] == [256, 256, 256] and c["volume_size"] == [2, 2, 2] and c["initial_pos_factor"] == [0.5, 0.5, 0]
-    assert c["pyramid"] == [10, 5, 4] and abs(c["mu"] - 0.1) < 1e-7 and abs(c["icp_threshold"] - 1e-5) < 1e-12 and c["camera_overrided"] == 0
-    # the reference Makefile's trajectory-2 line, long and short options mixed
-    r, c = run(probe, "-s", "4.8", "-p", "0.34,0.5,0.24", "-z", "4", "-c", "2", "--integration-rate", "1", "-k", "481.2,480,320,240",
-               "-v", "128", "-y", "8,4", "-l", "1e-6", "-m", "0.2", "-t", "2", "-o", "x.log", "-d", "vol.bin", "-q")
-    assert c["volume_size"] == [4.8, 4.8, 4.8] or np.allclose(c["volume_size"], [4.8] * 3)      # one value is broadcast
-    assert np.allclose(c["initial_pos_factor"], [0.34, 0.5, 0.24]) and c["volume_resolution"] == [128, 128, 128]
-    assert c["compute_size_ratio"] == 2 and c["integration_rate"] == 1 and c["tracking_rate"] == 2 and c["pyramid"] == [8, 4]
-    assert np.allclose(c["camera"], [481.2, 480, 320, 240]) and c["camera_overrided"] == 1 and c["no_gui"] == 1
-    assert c["log"] == "x.log" and c["dump"] == "vol.bin" and abs(c["mu"] - 0.2) < 1e-7
-    r, c = run(probe, "-v", "64,32")                      # two values: the third repeats the second
-    assert c["volume_resolution"] == [64, 32, 32]
-    for bad in (["-c", "3"], ["-r", "0"], ["-f", "-1"], ["-s", "-1"], ["-i", "/no/such/file"]):
-        r, _ = run(probe, *bad)
-        assert r.returncode == 1 and "ERROR" in r.stderr
-    r, _ = run(probe, "--bogus")
-    assert r.returncode == 0 and "Unknown option" in r.stderr
+@pytest.mark.parametrize("case", [c for c in VEC["read"] if c["path"] != "scene.raw"], ids=lambda c: c["path"] + ":" + c["what"])
+def test_cpp_readers_equal_the_reference_build(probe, work, case):
+    got = mk.run_read(probe, case["path"], case["what"], work)
+    assert got["meta"] == case["meta"]
+    assert (got["announced_end"], got["garbage"]) == (case["announced_end"], case["garbage"])
+    assert got["samples"] == case["samples"]
+    assert (got["bytes"], got["sha256"]) == (case["bytes"], case["sha256"])
 
 
-def _fnv(a):
-    h = 1469598103934665603
-    for v in a.reshape(-1).tolist():
-        h ^= v
-        h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    return h
+def _case(path, what):
+    return [c for c in VEC["read"] if c["path"] == path and c["what"] == what][0]
 
 
-def test_raw_reader_matches_python_twin(probe, tmp_path):
-    s = synth.make_stream(3, 64, 48)
-    path = str(tmp_path / "s.raw")
-    synth.write_raw(path, s)
-    r, out = run(probe, "--read", path)
-    assert out["w"] == 64 and out["h"] == 48 and out["type"] == 0 and np.allclose(out["k"], [531.15, 531.15, 320, 240])
-    assert out["frames"] == [_fnv(d) for d in rawio.RawDepthReader(path)]
-    assert "End of file" in r.stdout                     # interface.h:287-290: the reader announces the end on stdout
+def test_scene2raw_py_is_byte_identical_to_the_reference_tool(probe, work):
+    raw = os.path.join(work, "scene.raw")
+    assert scene2raw.convert(os.path.join(work, "scene"), raw) == host_inputs.SCENE_FRAMES
+    got = mk.digest(raw, "<u1")
+    want = VEC["scene2raw"]
+    assert got["bytes"] == want["bytes"] == host_inputs.SCENE_FRAMES * (16 + 640 * 480 * 5)
+    assert got["samples"] == want["samples"]
+    assert got["sha256"] == want["sha256"]
+    # and the C++ reader of this repo reads that file like the reference's reader reads the reference tool's file
+    c = _case("scene.raw", "u16")
+    got = mk.run_read(probe, "scene.raw", "u16", work)
+    assert (got["meta"], got["sha256"]) == (c["meta"], c["sha256"])
+    assert scene2raw.main(["scene2raw", "only-one-argument"]) == VEC["scene2raw_usage"]["returncode"] == 1
 
 
-def test_scene_reader_and_scene2raw(probe, tmp_path):
-    """ICL-NUIM ingestion: .depth files hold ray lengths; both the C++ reader and scene2raw turn them
-    into z-depth, the former in float32 (interface.h:181-193), the latter in double (scene2raw.cpp:76-113)."""
-    d = tmp_path / "scene"
-    d.mkdir()
-    rng = np.random.default_rng(4)
-    for i in range(2):
-        rays = rng.uniform(0.5, 4.0, size=640 * 480)
-        (d / ("scene_00_%04d.depth" % i)).write_text(" ".join("%.6f" % v for v in rays))
-    r, out = run(probe, "--read", str(d))
-    assert out["w"] == 640 and out["h"] == 480 and out["type"] == 1 and np.allclose(out["k"], [481.2, 480, 319.5, 239.5])
-    py = rawio.SceneDepthReader(str(d))
-    frames = [py.read_next_depth_frame(), py.read_next_depth_frame()]
-    assert py.read_next_depth_frame() is None and len(out["frames"]) == 2
-    for got, f in zip(out["frames"], frames):
-        # float32 division vs the C++ build can differ in the last bit before truncation: compare loosely per pixel
-        assert got == _fnv(f) or True
-    assert 400 < frames[0].mean() < 4000 and frames[0][240, 320] <= 4000
-    # scene2raw: double arithmetic, same geometry; centre pixel scale is ~1, corners shrink by ~1/1.28
-    raw = str(tmp_path / "scene.raw")
-    assert scene2raw.convert(str(d), raw) == 2
-    rd = rawio.RawDepthReader(raw)
-    z = rd.read_next_depth_frame()
-    assert z.shape == (480, 640) and np.abs(z.astype(np.int32) - frames[0].astype(np.int32)).max() <= 1
-    assert os.path.getsize(raw) == 2 * (16 + 640 * 480 * 5)
+def test_python_readers_equal_the_reference_build(work):
+    for name in ("in.raw", "tail.raw"):
+        c = _case(name, "u16")
+        frames = list(rawio.RawDepthReader(os.path.join(work, name)))
+        assert len(frames) == c["meta"]["frames"]
+        assert hashlib.sha256(b"".join(f.astype("<u2").tobytes() for f in frames)).hexdigest() == c["sha256"]
+    c = _case("vga.raw", "f32")
+    rd = rawio.RawDepthReader(os.path.join(work, "vga.raw"))
+    assert hashlib.sha256(rd.read_next_depth_frame_float().astype("<f4").tobytes()).hexdigest() == c["sha256"]
+    assert np.array_equal(np.array(rd.get_k(), np.float32).view(np.uint32), c["meta"]["k"])
+    for what in ("u16", "f32"):
+        c = _case("scene", what)
+        py = rawio.SceneDepthReader(os.path.join(work, "scene"))
+        assert np.array_equal(np.array(py.get_k(), np.float32).view(np.uint32), c["meta"]["k"])
+        frames = []
+        while True:
+            f = py.read_next_depth_frame() if what == "u16" else py.read_next_depth_frame_float()
+            if f is None:
+                break
+            frames.append(f)
+        assert len(frames) == c["meta"]["frames"]
+        assert hashlib.sha256(b"".join(f.tobytes() for f in frames)).hexdigest() == c["sha256"]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "host_probe")), reason="reference build absent (GPU box)")
+def test_golden_file_is_what_the_reference_build_prints_today(work):
+    """Build container only: the committed fixture is not stale."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "host_probe")
+    for case in VEC["config"]:
+        assert mk.run_config(ref, case["args"], work) == case
+    for case in VEC["read"]:
+        if case["path"] != "scene.raw":
+            assert mk.run_read(ref, case["path"], case["what"], work) == case
 
 
 def test_checkkernels_summary():

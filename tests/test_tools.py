@@ -61,6 +61,13 @@ def test_checkpos_matches_the_reference_conventions(tmp_path):
     del text[3]
     log = checkpos.parse_log("\n".join(text))
     assert log["dropped"] == 1 and len(log["traj"]) == 6
+    # ... and then ATE_wrt_kfusion scores the frames that were processed only (checkPos.py:99,127-128,147-148);
+    # without dropped frames the row is not reported
+    rep = checkpos.summarise("\n".join(text), open(gt_path).read())
+    padded = np.linalg.norm(disp[2] - disp[1])             # the dropped frame 2 repeats frame 1's position
+    assert abs(rep["ATE"]["max"] - padded) < 1e-6 and abs(rep["ATE"]["total"] - padded) < 5e-6
+    assert rep["ATE_wrt_kfusion"]["max"] < 1e-6 and rep["_meta"]["dropped"] == 1
+    assert "ATE_wrt_kfusion" not in checkpos.summarise(_fake_log(disp, [1] * 6), open(gt_path).read())
 
 
 def test_benchmark_cli_rejects_bad_flags():
