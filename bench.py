@@ -2,27 +2,35 @@
 """Throughput bench of the KinectFusion hot path on MI355X (contract: see DESIGN.md "Measurement").
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --raw living_room_traj2_loop.raw --gt livingRoom2.gt.freiburg      (real ICL-NUIM data, when present;
+                                                             or KFH_ICL_NUIM_DIR=<dir holding the Makefile's file names>)
 
 One *step* is one frame through preprocessing -> tracking (multi-level ICP) -> integration -> raycasting —
 the reference's `computation` column (kfusion/src/benchmark.cpp:164), the figure its README quotes — on the
 configuration BASELINE.json's metric is quoted on: 640x480 depth, `-c 1 -v 256 -y 10,5,4` and the reference
 Makefile's trajectory-2 flags `-s 4.8 -p 0.34,0.5,0.24 -k 481.2,480,320,240 -r 2`.  Depth frames are a seeded
-synthetic stream (no dataset offline) already resident in HBM when the timed region starts.  With N GPUs every
-rank runs its own independent stream (frames shard by stream; no data-path collective) and RCCL is used only
-for the barrier and the max-over-ranks time.
+synthetic stream (no dataset offline) already resident in HBM when the timed region starts, and frames are QUEUED
+(kfh_compute_frame, no host round trip per frame).  With N GPUs every rank runs its own independent stream
+(frames shard by stream; no data-path collective) and RCCL is used only for the barriers and one all-reduce.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries `roofline` (dominant kernel,
-algorithmic bytes / HIP-event time measured in this run), `cpu_baseline` (the OpenMP oracle timed on the host
-cores on a bounded prefix of the same stream), `fps_total` (same loop plus the three renders and their
-read-back) and the ATE of the estimated trajectory against the generator's ground truth.
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline / roofline_other   icp loop, k_integrate, k_raycast: algorithmic bytes / HIP-event time measured in this run
+  cpu_baseline                the OpenMP oracle timed on the host cores on a bounded prefix of the same stream
+  fps_total                   the same queued loop plus the three renders and their read-back
+  fps_host_buffers            what a reference-style caller gets (benchmark.cpp:125-158): kfusion-benchmark-hip itself on a
+                              `.raw` of the same frames - pageable host depth, four phase calls, a device sync at every tock()
+  ate_m                       ATE of the estimated trajectory, scored as checkPos.py scores a log
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
+import types
 
 import numpy as np
 
@@ -39,6 +47,7 @@ CONFIGS = {
     "cfg4": (1280, 960, 512, (10, 5, 4, 4), 2, 4),    # configs[3]: 4-level ICP
 }
 MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, float(os.environ.get("KFH_DEBUG_ICP_THRESHOLD", "1e-5")), 1
+V_FRAMES = 2            # frames after the cpu_baseline prefix on which the oracle counts V (distinct voxels a raycast samples)
 
 
 def icp_launches(pyramid, head=4):
@@ -58,67 +67,128 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--raw", default=None, help="real data: a SLAMBench .raw file or an ICL-NUIM scene directory (default: "
+                    "$KFH_ICL_NUIM_DIR/living_room_traj<N>_loop.raw when present, else the synthetic stream)")
+    ap.add_argument("--gt", default=None, help="ground truth of --raw in freiburg format (livingRoom<N>.gt.freiburg)")
+    ap.add_argument("--traj", type=int, default=None, help="ICL-NUIM trajectory 0-3: picks the Makefile's -s/-p/-k line (default: from the file name, else 2)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-total", action="store_true", help="skip the secondary loop with renders")
-    ap.add_argument("--profile-every", type=int, default=8,
-                    help="HIP-event pairs around icp/integrate/raycast on every n-th timed frame (0 = none; 1 = every "
-                         "frame, which costs ~23 us per frame in queue drains)")
+    ap.add_argument("--no-host-buffers", action="store_true", help="skip the kfusion-benchmark-hip leg (fps_host_buffers)")
+    ap.add_argument("--profile-every", type=int, default=None,
+                    help="an HIP-event pair around ONE of icp/integrate/raycast (rotating) on every n-th timed frame; default "
+                         "steps/10 clamped to 1..8; 0 = none")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent RGB-D streams processed concurrently on each GPU (throughput mode; the headline is 1)")
     return ap.parse_args()
 
 
-def run_gpu(kfusion, torch, stream, d_depth, cfg, device, n_warm, n_steps, with_renders, dist, extra_streams=0, prof_every=8):
-    """Warm up on frames [0, n_warm), time frames [n_warm, n_warm + n_steps).  Returns (seconds, kf).
-    extra_streams > 0 runs that many more independent contexts (same input stream) interleaved with the first one."""
-    W, H, vres, pyramid, irate, zrate = cfg
-    k = list(stream.k)
-    kf = kfusion.Kfusion((W, H), (vres,) * 3, (4.8,) * 3, stream.init_pos, pyramid, device=device)
-    others = [kfusion.Kfusion((W, H), (vres,) * 3, (4.8,) * 3, stream.init_pos, pyramid, device=device) for _ in range(extra_streams)]
-    frame_bytes = W * H * 2
-    base = d_depth.data_ptr()
-    renders = [np.zeros((H, W, 4), np.uint8) for _ in range(3)] if with_renders else None
-    import ctypes as C
+def load_workload(args, rank, n_frames, W, H):
+    """The depth stream of this rank and the scene parameters that go with it.  Returns a namespace with depth_mm (n, H, W)
+    uint16, k, init_pos, volume_size, gt_rows (or None), data label, and the trajectory record when the data is real."""
+    from slambench_amd import checkpos, multi, rawio, synth, trajectories
+    raw, gt = args.raw, args.gt
+    if raw is None:
+        idx = args.traj if args.traj is not None else (2 if multi.env_rank()[0] == 1 else rank % multi.N_TRAJECTORIES)
+        found = trajectories.find_dataset(None, idx)
+        if found:
+            raw, gt = found[0], gt or found[1]
+    if raw is None:
+        s = synth.cached_stream(n_frames, W, H, seed=1234, variant=multi.stream_variant(rank))
+        return types.SimpleNamespace(depth_mm=s.depth_mm, k=tuple(s.k), init_pos=np.asarray(s.init_pos, np.float32), volume_size=4.8,
+                                     init_factors=(0.34, 0.5, 0.24), gt_rows=[tuple(g) for g in synth.ground_truth_rows(s)], data="synthetic",
+                                     source=None, width=W, height=H, write_raw=lambda path, n: synth.write_raw(path, types.SimpleNamespace(
+                                         width=W, height=H, depth_mm=s.depth_mm[:n])))
+    idx = args.traj if args.traj is not None else trajectories.guess_index(raw)
+    t = trajectories.TRAJECTORIES[idx]
+    reader = rawio.RawDepthReader(raw) if os.path.isfile(raw) else rawio.SceneDepthReader(raw)
+    if tuple(reader.get_input_size()) != (W, H):
+        raise SystemExit("--raw holds %dx%d frames, config %s needs %dx%d" % (*reader.get_input_size(), args.config, W, H))
+    frames = []
+    while len(frames) < n_frames:
+        d = reader.read_next_depth_frame()
+        if d is None:
+            break
+        frames.append(d)
+    if len(frames) < n_frames:
+        raise SystemExit("%s holds %d frames, --warmup + --steps (+%d) need %d" % (raw, len(frames), V_FRAMES, n_frames))
+    gt_rows = checkpos.parse_freiburg(open(gt).read()) if gt else None
+    return types.SimpleNamespace(depth_mm=np.stack(frames), k=t.camera, init_pos=t.init_position(), volume_size=t.volume_size,
+                                 init_factors=t.init_pose, gt_rows=gt_rows, data="icl-nuim living_room_traj%d" % idx, source=raw if os.path.isfile(raw) else None,
+                                 width=W, height=H, write_raw=None)
 
-    def step(f):
-        kf.compute_frame(base + f * frame_bytes, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
-        for o in others:
-            o.compute_frame(base + f * frame_bytes, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
-        if with_renders:   # benchmark.cpp:153-156
-            L, h = kf.L, kf.h
+
+class Leg:
+    """One context (plus optional extra ones) stepping through the stream with kfh_compute_frame."""
+
+    def __init__(self, kfusion, wl, d_depth, cfg, device, with_renders, extra_streams=0):
+        W, H, vres, pyramid, irate, zrate = cfg
+        self.cfg, self.wl, self.with_renders = cfg, wl, with_renders
+        mk = lambda: kfusion.Kfusion((W, H), (vres,) * 3, (wl.volume_size,) * 3, wl.init_pos, pyramid, device=device)
+        self.kf = mk()
+        self.others = [mk() for _ in range(extra_streams)]
+        self.base, self.frame_bytes = d_depth.data_ptr(), W * H * 2
+        self.renders = [np.zeros((H, W, 4), np.uint8) for _ in range(3)] if with_renders else None
+
+    def step(self, f):
+        import ctypes as C
+        W, H, _, _, irate, zrate = self.cfg
+        k = list(self.wl.k)
+        for ctx in [self.kf] + self.others:
+            ctx.compute_frame(self.base + f * self.frame_bytes, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
+        if self.with_renders:   # benchmark.cpp:153-156
+            L, h = self.kf.L, self.kf.h
             u8 = C.POINTER(C.c_uint8)
-            L.kfh_render_depth(h, renders[0].ctypes.data_as(u8), W, H)
-            L.kfh_render_track(h, renders[1].ctypes.data_as(u8), W, H)
-            L.kfh_render_volume(h, renders[2].ctypes.data_as(u8), W, H, f, zrate, (C.c_float * 4)(*k), 0.75 * MU)
+            L.kfh_render_depth(h, self.renders[0].ctypes.data_as(u8), W, H)
+            L.kfh_render_track(h, self.renders[1].ctypes.data_as(u8), W, H)
+            L.kfh_render_volume(h, self.renders[2].ctypes.data_as(u8), W, H, f, zrate, (C.c_float * 4)(*k), 0.75 * MU)
 
-    for f in range(n_warm):
-        step(f)
-    kf.synchronise()
-    for o in others:
-        o.synchronise()
-    if not with_renders and prof_every > 0:
-        kf.set_profiling(["icp", "integrate", "raycast"], every=prof_every)
+    def sync(self):
+        for ctx in [self.kf] + self.others:
+            ctx.synchronise()
+
+    def close(self):
+        for ctx in [self.kf] + self.others:
+            ctx.close()
+
+
+def timed_run(make_leg, torch, dist, multi, n_warm, n_steps, prof_every, coll_device):
+    """Warm up on frames [0, n_warm), time frames [n_warm, n_warm + n_steps) between barrier + synchronize pairs.
+    A rank that fails still takes part in every collective, so the job ends with the reason instead of a watchdog kill."""
+    leg, err = None, None
+    try:
+        leg = make_leg()
+        for f in range(n_warm):
+            leg.step(f)
+        leg.sync()
+        if prof_every > 0 and not leg.with_renders:
+            leg.kf.set_profiling(["icp", "integrate", "raycast"], every=prof_every, rotate=True)
+    except Exception as e:       # noqa: BLE001
+        err = e
+    if not multi.all_ok(err is None, dist, coll_device):
+        if err is not None:
+            print("bench.py: rank %d failed before the timed region: %r" % (multi.env_rank()[1], err), file=sys.stderr)
+        raise SystemExit(1)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for f in range(n_warm, n_warm + n_steps):
-        step(f)
-    kf.synchronise()
-    for o in others:
-        o.synchronise()
+    try:
+        for f in range(n_warm, n_warm + n_steps):
+            leg.step(f)
+        leg.sync()
+    except Exception as e:       # noqa: BLE001
+        err = e
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    for o in others:
-        o.close()
     if dist is not None:
         dist.barrier()
-    return elapsed, kf
+    return elapsed, leg, err
 
 
-def cpu_baseline(stream, cfg, budget_s, max_frames):
-    """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only)."""
+def cpu_baseline(wl, cfg, budget_s, max_frames):
+    """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only); then V of
+    SURVEY §8(d) - the distinct voxels one raycast samples - counted by the oracle on the V_FRAMES frames that follow the prefix."""
     from oracle import orc
     orc.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -130,32 +200,76 @@ def cpu_baseline(stream, cfg, budget_s, max_frames):
         pass
     os.environ["OMP_NUM_THREADS"] = str(cores)
     W, H, vres, pyramid, irate, _ = cfg
-    k = list(stream.k)
-    o = orc.OracleKfusion((W, H), (vres,) * 3, (4.8,) * 3, stream.init_pos, pyramid, omp=True)
+    k = list(wl.k)
+    o = orc.OracleKfusion((W, H), (vres,) * 3, (wl.volume_size,) * 3, wl.init_pos, pyramid, omp=True)
+
+    def frame(f):
+        o.preprocessing(wl.depth_mm[f]); o.tracking(k, ICP_THRESHOLD, TRACKING_RATE, f)
+        o.integration(k, irate, MU, f); o.raycasting(k, MU, f)
+
     n, spent = 0, 0.0
-    while n < max_frames and (spent < budget_s or n < 8):
+    timed_max = max(1, min(max_frames, wl.depth_mm.shape[0]) - V_FRAMES)
+    while n < timed_max and (spent < budget_s or n < 8):
         t = time.perf_counter()
-        o.preprocessing(stream.depth_mm[n]); o.tracking(k, ICP_THRESHOLD, TRACKING_RATE, n)
-        o.integration(k, irate, MU, n); o.raycasting(k, MU, n)
+        frame(n)
         spent += time.perf_counter() - t
         n += 1
-    # V of SURVEY §8(d) (distinct voxels a raycast samples) — counted on two more frames, outside the timing
     o.set_counting(True)
     vs = []
-    for f in range(n, min(n + 2, max_frames)):
-        o.preprocessing(stream.depth_mm[f]); o.tracking(k, ICP_THRESHOLD, TRACKING_RATE, f)
-        o.integration(k, irate, MU, f); o.raycasting(k, MU, f)
-        vs.append(o.counters()["raycast_distinct_voxels"])
+    for f in range(n, min(n + V_FRAMES, wl.depth_mm.shape[0])):
+        frame(f)
+        if f > 2:                                        # cpp:977: no raycast before frame 3
+            vs.append(o.counters()["raycast_distinct_voxels"])
     o.close()
-    return {"value": n / spent, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(n / spent, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "first %d frames of the same stream, OpenMP oracle (liborc_omp.so), %d threads, %.1f s" % (n, cores, spent)}, \
         (float(np.mean(vs)) if vs else None)
+
+
+def host_buffers_leg(wl, cfg, n_frames):
+    """kfusion-benchmark-hip (the drop-in driver, reference call sequence benchmark.cpp:125-158) on a .raw of the same frames."""
+    from slambench_amd import build, checkpos
+    W, H, vres, pyramid, irate, zrate = cfg
+    exe = build.BENCH_BIN
+    if not os.path.exists(exe):
+        return {"error": "kfusion-benchmark-hip is not built"}
+    tmp = None
+    try:
+        if wl.source:
+            raw = wl.source
+        else:
+            n = int(max(16, min(n_frames, 60, (128 << 20) // (W * H * 5 + 16))))
+            n = min(n, wl.depth_mm.shape[0])
+            tmp = tempfile.mkdtemp(prefix="kfh_bench_")
+            raw = os.path.join(tmp, "stream.raw")
+            wl.write_raw(raw, n)
+        log = os.path.join(tmp or tempfile.gettempdir(), "kfh_bench_%d.log" % os.getpid())
+        cmd = [exe, "-i", raw, "-o", log, "-s", "%g" % wl.volume_size, "-p", ",".join("%g" % v for v in wl.init_factors), "-z", str(zrate),
+               "-c", "1", "-r", str(irate), "-k", ",".join("%g" % v for v in wl.k), "-v", str(vres), "-y", ",".join(map(str, pyramid)),
+               "-m", "%g" % MU, "-l", "%g" % ICP_THRESHOLD]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": "driver exit %d: %s" % (r.returncode, r.stderr[-300:])}
+        cols = checkpos.parse_log(open(log).read())["columns"]
+        n = len(cols["computation"])
+        skip = min(10, n // 3)                          # first frames: lazy initialisation, frames 0-3 are not tracked
+        comp, tot = cols["computation"][skip:], cols["total"][skip:]
+        return {"computation": round(len(comp) / sum(comp), 2), "total": round(len(tot) / sum(tot), 2), "unit": "frames/s", "frames": len(comp),
+                "computation_ms": round(1e3 * sum(comp) / len(comp), 4),
+                "what": "kfusion-benchmark-hip on a .raw of the same stream: pageable host depth through preprocessing(), four phase calls, "
+                        "synchroniseDevices() at every tock() (benchmark.cpp:26-39,125-158); PCIe-inclusive, never the headline value"}
+    except Exception as e:       # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        if tmp:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
     args = parse()
     import torch
-    from slambench_amd import checkpos, kfusion, multi, synth
+    from slambench_amd import checkpos, kfusion, multi
 
     world, rank, local_rank = multi.env_rank()
     dist = None
@@ -178,54 +292,79 @@ def main():
         local_rank = 0
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     coll_device = "cuda" if (dist is None or os.environ.get("KFH_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
+    try:
+        run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusion, multi)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
 
+
+def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusion, multi):
     cfg = CONFIGS[args.config]
     if os.environ.get("KFH_DEBUG_PYRAMID"):    # experiments only (cost of the queued-but-empty ICP launches)
         cfg = cfg[:3] + (tuple(int(v) for v in os.environ["KFH_DEBUG_PYRAMID"].split(",")),) + cfg[4:]
     W, H, vres, pyramid, irate, zrate = cfg
     n_frames = args.warmup + args.steps
+    prof_every = args.profile_every if args.profile_every is not None else max(1, min(8, args.steps // 10))
     # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
-    stream = synth.cached_stream(n_frames, W, H, seed=1234, variant=multi.stream_variant(rank))
-    d_depth = torch.from_numpy(stream.depth_mm.view(np.int16)).cuda()
+    wl = load_workload(args, rank, n_frames + V_FRAMES, W, H)
+    d_depth = torch.from_numpy(wl.depth_mm.view(np.int16)).cuda()
 
     spg = max(1, args.streams_per_gpu)
-    elapsed, kf = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, False, dist, spg - 1,
-                          args.profile_every)
-    prof = kf.read_profile()
-    updated = kf.integrate_updated()
-    icp_iters = kf.icp_iterations()
-    icp_by_level = kf.icp_level_iterations()
-    if kf.barrier_timeouts():
-        raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
-    fallbacks = kf.solve_fallbacks()
-    poses, tracked, integrated = kf.frame_log(n_frames)
-    kf.close()
-
-    # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
-    pos_after = poses[:, :3, 3] - stream.init_pos.astype(np.float32)
-    rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
-    errs = checkpos.ate([tuple(r) for r in rows], [tuple(g) for g in synth.ground_truth_rows(stream)])
+    elapsed, leg, err = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, spg - 1), torch, dist, multi,
+                                  args.warmup, args.steps, prof_every, coll_device)
+    failed, errs = 0, [0.0]
+    prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = None
+    try:
+        if err is not None:
+            raise err
+        kf = leg.kf
+        prof = kf.read_profile()
+        updated = kf.integrate_updated()
+        icp_iters = kf.icp_iterations()
+        icp_by_level = kf.icp_level_iterations()
+        if kf.barrier_timeouts():
+            raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
+        fallbacks = kf.solve_fallbacks()
+        poses, tracked, integrated = kf.frame_log(n_frames)
+        leg.close()
+        # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
+        if wl.gt_rows is not None:
+            pos_after = poses[:, :3, 3] - wl.init_pos.astype(np.float32)
+            rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
+            errs = checkpos.ate([tuple(r) for r in rows], wl.gt_rows)
+    except Exception as e:       # noqa: BLE001
+        failed = 1
+        print("bench.py: rank %d failed: %r" % (rank, e), file=sys.stderr)
 
     # whole-job aggregate: frames summed over ranks / max time over ranks (one small all-reduce on RCCL)
-    job = multi.aggregate(multi.RankStats(args.steps * spg, elapsed, float(np.sum(errs)), float(np.max(errs)), int((tracked == 0).sum())),
-                          dist, device=coll_device)
+    job = multi.aggregate(multi.RankStats(args.steps * spg, elapsed, float(np.sum(errs)), float(np.max(errs)),
+                                          0 if tracked is None else int((tracked == 0).sum()), failed), dist, device=coll_device)
+    if job.failed:
+        raise SystemExit("bench.py: %d rank(s) failed - no result" % job.failed)
     t_max, total_frames = job.seconds, job.frames
-    ate = {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs), "untracked_all_ranks": job.untracked}
+    ate = None if wl.gt_rows is None else {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs),
+                                           "untracked_all_ranks": job.untracked}
 
     fps_total = None
     if not args.no_total:
-        e2, kf2 = run_gpu(kfusion, torch, stream, d_depth, cfg, local_rank, args.warmup, args.steps, True, dist)
-        kf2.close()
-        fps_total = multi.aggregate(multi.RankStats(args.steps, e2), dist, device=coll_device).fps
+        e2, leg2, err2 = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, True), torch, dist, multi, args.warmup, args.steps, 0, coll_device)
+        if leg2 is not None:
+            leg2.close()
+        j2 = multi.aggregate(multi.RankStats(args.steps, e2, failed=0 if err2 is None else 1), dist, device=coll_device)
+        fps_total = None if j2.failed else j2.fps
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     cpu, v_distinct = (None, None)
     if not args.no_cpu_baseline and world == 1:
-        cpu, v_distinct = cpu_baseline(stream, cfg, args.cpu_seconds, n_frames)
+        cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, n_frames + V_FRAMES)
+    host = None
+    if not args.no_host_buffers and world == 1:
+        del d_depth
+        torch.cuda.empty_cache()
+        host = host_buffers_leg(wl, cfg, n_frames)
 
     # HBM bytes per launch from the PMC passes of profiles/collect_traffic.sh (rocprofv3 cannot wrap this process from
     # inside); null when no measurement of this configuration is committed
@@ -251,13 +390,20 @@ def main():
             continue
         avg_s = ms / n * 1e-3
         if name == "integrate":
-            alg = 8.0 * (updated / max(1, int(integrated.sum()))) + 4.0 * P      # 8*U + 4*P  
+            u_per_launch = updated / max(1, int(integrated.sum()))
+            alg = 8.0 * u_per_launch + 4.0 * P                                   # 8*U + 4*P  
+            detail = {"U_voxels_updated_per_launch": round(u_per_launch)}
         else:
-            alg = 24.0 * P + 4.0 * (v_distinct if v_distinct else 0.0)            # 24*P + 4*V
+            if v_distinct is None:                                                # no oracle count in this run: say so, report no fraction
+                roof[name] = {"kernel": "k_raycast", "bound": "hbm", "avg_us": round(avg_s * 1e6, 2), "launches": n, "achieved": None,
+                              "frac": None, "note": "V (distinct voxels sampled) is counted by the CPU oracle: run without --no-cpu-baseline"}
+                continue
+            alg = 24.0 * P + 4.0 * v_distinct                                     # 24*P + 4*V
+            detail = {"V_distinct_voxels_sampled": round(v_distinct)}
         gbs = alg / avg_s / 1e9
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n, "sampled_every_n_frames": args.profile_every,
-                      "algorithmic_bytes_per_launch": round(alg)}
+                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                      "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg), **detail}
     # The ICP loop of a frame (k_icp_iter* launches, k_icp_tail for the late iterations of a level, k_icp_final): 48 bytes per associated pixel (two float4 input
     # maps, a 32-byte gather from the reference maps) for every EXECUTED iteration, plus - on the queued-frame path - the
     # next frame's bilateral filter (2P in, 8P out) and pyramid (4P in, 36 bytes per pixel of every level out) that ride
@@ -266,38 +412,37 @@ def main():
     if n:
         levels = len(pyramid)
         px = [(W >> l) * (H >> l) for l in range(levels)]
-        alg = 48.0 * sum(icp_by_level[l] * px[l] for l in range(levels)) / max(1, n_frames)
-        alg += 10.0 * P + 4.0 * P + 36.0 * sum(px)
+        alg_icp = 48.0 * sum(icp_by_level[l] * px[l] for l in range(levels)) / max(1, n_frames)
+        alg_pre = 10.0 * P + 4.0 * P + 36.0 * sum(px)
+        alg = alg_icp + alg_pre
         avg_s = ms / n * 1e-3
         gbs = alg / avg_s / 1e9
         roof["icp"] = {"kernel": "k_icp_iter* + k_icp_tail (one frame's ICP loop: %d queued iterations in %d launches)" % (sum(pyramid), icp_launches(pyramid)), "bound": "hbm",
                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                        "traffic": traffic.get("icp"), "avg_us": round(avg_s * 1e6, 2), "launches": n,
-                       "sampled_every_n_frames": args.profile_every, "algorithmic_bytes_per_launch": round(alg),
+                       "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg),
+                       "of_which_next_frame_preprocessing_bytes": round(alg_pre),
                        "executed_iterations_per_frame_by_level": [round(v / max(1, n_frames), 2) for v in icp_by_level]}
     dominant = max(roof, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if roof else None
-    if spg > 1:
-        args.steps_label = "%d frames x %d streams" % (args.steps, spg)
     out = {
-        "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), living-room-like stream 640x480 -c 1 @256^3",
+        "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), device-resident input, queued frames, "
+                  "living-room stream %dx%d -c 1 @%d^3" % (W, H, vres),
         "value": round(total_frames / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t_max / (args.steps * spg) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d depth, -c 1 -v %d -y %s -r %d -z %d -s 4.8 -p 0.34,0.5,0.24 -k 481.2,480,320,240 -m 0.1, one stream per GPU"
-                               % (args.config, W, H, vres, ",".join(map(str, pyramid)), irate, zrate),
+        "dtype": "f32", "data": wl.data,
+        "config": {"workload": "%s: %dx%d depth, -c 1 -v %d -y %s -r %d -z %d -s %g -p %s -k %s -m 0.1, one stream per GPU"
+                               % (args.config, W, H, vres, ",".join(map(str, pyramid)), irate, zrate, wl.volume_size,
+                                  ",".join("%g" % v for v in wl.init_factors), ",".join("%g" % v for v in wl.k)),
                    "frames_per_gpu": args.steps * spg, "streams_per_gpu": spg, "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks},
         "fps_total": None if fps_total is None else round(fps_total, 2),
+        "fps_host_buffers": host,
         "ate_m": ate,
         "phase_us": {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items() if v[1]},
         "roofline": roof.get(dominant),
         "roofline_other": {k: v for k, v in roof.items() if k != dominant},
         "cpu_baseline": cpu,
     }
-    if args.config != "cfg2":
-        out["metric"] = out["metric"].replace("640x480 -c 1 @256^3", "%dx%d -c 1 @%d^3" % (W, H, vres))
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -42,6 +42,14 @@ class Kfusion {
             std::exit(1);   // the reference backends exit(1) on fatal set-up errors
         }
     }
+    // a negative verdict is a device-side failure (rejected launch, ICP barrier time-out): fatal, like the reference's set-up errors
+    static int checked(int r, const char *what) {
+        if (r < 0 && r != KFH_ERR_INVALID_RATIO) {
+            std::fprintf(stderr, "%s failed (%d): %s\n", what, r, kfh_last_error());
+            std::exit(1);
+        }
+        return r;
+    }
     static void k4(const float4 &k, float out[4]) { out[0] = k.x; out[1] = k.y; out[2] = k.z; out[3] = k.w; }
 
 public:
@@ -84,30 +92,31 @@ public:
         const int r = kfh_compute_frame(ctx_, inputDepth, 0, inputSize.x, inputSize.y, kk, integration_rate, tracking_rate,
                                         icp_threshold, mu, frame);
         if (r == KFH_ERR_INVALID_RATIO) std::exit(1);   // cpp/kernels.cpp:566-576
-        tracked_ = kfh_get_tracked(ctx_) != 0;
-        integrated_ = kfh_get_integrated(ctx_) != 0;
+        checked(r, "Kfusion::computeFrame");
+        tracked_ = checked(kfh_get_tracked(ctx_), "Kfusion::computeFrame") != 0;
+        integrated_ = checked(kfh_get_integrated(ctx_), "Kfusion::computeFrame") != 0;
     }
 
     bool preprocessing(const ushort *inputDepth, const uint2 inputSize) {
         const int r = kfh_preprocessing(ctx_, inputDepth, inputSize.x, inputSize.y);
         if (r == KFH_ERR_INVALID_RATIO) std::exit(1);
-        return r > 0;
+        return checked(r, "Kfusion::preprocessing") > 0;
     }
     bool tracking(float4 k, float icp_threshold, uint tracking_rate, uint frame) {
         float kk[4];
         k4(k, kk);
-        tracked_ = kfh_tracking(ctx_, kk, icp_threshold, tracking_rate, frame) > 0;
+        tracked_ = checked(kfh_tracking(ctx_, kk, icp_threshold, tracking_rate, frame), "Kfusion::tracking") > 0;
         return tracked_;
     }
     bool raycasting(float4 k, float mu, uint frame) {
         float kk[4];
         k4(k, kk);
-        return kfh_raycasting(ctx_, kk, mu, frame) > 0;
+        return checked(kfh_raycasting(ctx_, kk, mu, frame), "Kfusion::raycasting") > 0;
     }
     bool integration(float4 k, uint integration_rate, float mu, uint frame) {
         float kk[4];
         k4(k, kk);
-        integrated_ = kfh_integration(ctx_, kk, integration_rate, mu, frame) > 0;
+        integrated_ = checked(kfh_integration(ctx_, kk, integration_rate, mu, frame), "Kfusion::integration") > 0;
         return integrated_;
     }
 

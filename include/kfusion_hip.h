@@ -32,6 +32,7 @@ extern "C" {
 #define KFH_ERR_HIP (-2)
 #define KFH_ERR_ARGUMENT (-3)
 #define KFH_ERR_IO (-4)
+#define KFH_ERR_BARRIER (-5)   /* the ICP grid barrier timed out (device oversubscribed): the frame's pose was rolled back */
 #define KFH_MAX_LEVELS 8
 
 typedef struct kfh_context kfh_context;
@@ -80,7 +81,11 @@ int kfh_preprocessing(kfh_context *ctx, const uint16_t *host_depth_mm, uint32_t 
 /* Same, input already resident in HBM (used by bench.py; the timed region excludes PCIe). */
 int kfh_preprocessing_device(kfh_context *ctx, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height);
 /* bool Kfusion::tracking(float4 k, float icp_threshold, uint tracking_rate, uint frame)  cpp/kernels.cpp:924-971
- * Returns 1 tracked / 0 not tracked. */
+ * Returns 1 tracked / 0 not tracked, or a sticky KFH_ERR_* (< 0) once the context has failed: a kernel launch the runtime
+ * rejected (KFH_ERR_HIP, the kernel is named in kfh_last_error()) or a time-out of the ICP grid barrier (KFH_ERR_BARRIER:
+ * the affected frame's pose was rolled back on the device and the frame counts as not tracked).  The same holds for
+ * kfh_integration, kfh_raycasting, kfh_compute_frame and the two verdict getters; include/kfusion/kernels.h turns it into
+ * the reference's behaviour for fatal errors (message on stderr, exit(1)). */
 int kfh_tracking(kfh_context *ctx, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame);
 /* bool Kfusion::integration(float4 k, uint integration_rate, float mu, uint frame)   cpp/kernels.cpp:988-1004 */
 int kfh_integration(kfh_context *ctx, const float k[4], uint32_t integration_rate, float mu, uint32_t frame);
@@ -108,6 +113,8 @@ void kfh_set_pose(kfh_context *ctx, const float in16[16]);
 void kfh_get_position(kfh_context *ctx, float out3[3]);
 int kfh_get_tracked(kfh_context *ctx);
 int kfh_get_integrated(kfh_context *ctx);
+/* KFH_OK, or the sticky error of the context (see kfh_tracking); synchronises, so it also covers every queued frame. */
+int kfh_get_error(kfh_context *ctx);
 void kfh_set_view_pose(kfh_context *ctx, const float *view_pose16_or_null);
 void kfh_get_model_dimensions(kfh_context *ctx, float out3[3]);
 void kfh_get_model_resolution(kfh_context *ctx, uint32_t out3[3]);
@@ -149,6 +156,10 @@ void kfh_set_profiling(kfh_context *ctx, uint32_t phase_mask);
  * record drains the queue for ~5 us on this GPU (measured: 6 records per frame cost 23 us of a 235 us frame), so a
  * benchmark that wants per-kernel times AND an undisturbed frame rate samples them.  Default 1. */
 void kfh_set_profiling_stride(kfh_context *ctx, uint32_t every_n_frames);
+/* Queued frames only: a sampled frame times ONE of icp / integrate / raycast - the phase sampled least so far among
+ * those the frame runs (integrate is skipped on frames with frame % integration_rate != 0) - so every phase collects
+ * samples whatever the stride and the rates are, and a sampled frame pays for one event pair instead of three. */
+void kfh_set_profiling_rotation(kfh_context *ctx, int32_t one_phase_per_sampled_frame);
 int kfh_read_profile(kfh_context *ctx, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]);
 
 /* Copy an internal device buffer to the host for parity checks.  name is one of

@@ -91,6 +91,7 @@ def lib(omp: bool = False):
         "orc_kfusion_dump_volume": (i, [vp, C.c_char_p]),
         "orc_kfusion_counters": (cp, [vp]),
         "orc_kfusion_set_counting": (None, [vp, i]),
+        "orc_set_omp_reduce_mode": (None, [i]),
         "orc_kfusion_buffer": (vp, [vp, C.c_char_p, C.POINTER(C.c_ulonglong)]),
     }
     for name_, (res, args) in sig.items():
@@ -99,6 +100,12 @@ def lib(omp: bool = False):
         fn.argtypes = args
     _libs[name] = L
     return L
+
+
+def set_omp_reduce_mode(reference_style: bool) -> None:
+    """-fopenmp build: True = the reduction is parallelised like the reference's OpenMP build (re-associated, SURVEY N8);
+    False (default) = bit-identical to the serial build."""
+    lib(True).orc_set_omp_reduce_mode(1 if reference_style else 0)
 
 
 def _p(a, t):

@@ -356,10 +356,48 @@ void orc_track(void *output, const float *inVertex, const float *inNormal, unsig
 // float32 running sums; rows 1..7 then added into row 0.  The OpenMP twin parallelises
 // over the 8 blocks only, which keeps this order (the reference's own OpenMP reduction
 // clause does not: SURVEY N8).
+// How the -fopenmp build parallelises the reduction.  0 (default): over the 8 row classes - every class keeps its serial
+// chain, so the result is bit-identical to the serial build (what the parity tests need).  1: as the reference's OpenMP
+// build does it (cpp:295-296, `#pragma omp parallel for reduction(+:sums0..31)` over the rows of a class): each thread
+// adds up its share of the rows and the shares are combined - a re-associated fp32 sum that depends on the thread count
+// (SURVEY N8).  Mode 1 is what tests/test_hip_fullsize.py measures the reference's own CPP-vs-OpenMP noise floor with.
+static int g_reduce_mode = 0;
+void orc_set_omp_reduce_mode(int reference_style) { g_reduce_mode = reference_style ? 1 : 0; }
+
+#ifdef _OPENMP
+static void reduce_rows_reference_omp(float *out, const TrackRec *J, unsigned JW, unsigned W, unsigned H) {
+    for (int b = 0; b < 8; ++b) {
+        float s[32];
+        for (int i = 0; i < 32; ++i) s[i] = 0.0f;
+#pragma omp parallel for schedule(static) reduction(+ : s[:32])
+        for (unsigned y = b; y < H; y += 8)
+            for (unsigned x = 0; x < W; ++x) {
+                const TrackRec &row = J[x + y * JW];
+                if (row.result < 1) {
+                    s[29] += row.result == -4 ? 1 : 0;
+                    s[30] += row.result == -5 ? 1 : 0;
+                    s[31] += row.result > -4 ? 1 : 0;
+                    continue;
+                }
+                s[0] += row.error * row.error;
+                for (int i = 0; i < 6; ++i) s[1 + i] += row.error * row.J[i];
+                int k = 7;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = r; c < 6; ++c) s[k++] += row.J[r] * row.J[c];
+                s[28] += 1;
+            }
+        for (int i = 0; i < 32; ++i) out[b * 32 + i] = s[i];
+    }
+    for (int j = 1; j < 8; ++j)
+        for (int i = 0; i < 32; ++i) out[i] += out[j * 32 + i];
+}
+#endif
+
 void orc_reduce(float *out, const void *Jv, unsigned JW, unsigned JH, unsigned W, unsigned H) {
     (void)JH;
     const TrackRec *J = static_cast<const TrackRec *>(Jv);
 #ifdef _OPENMP
+    if (g_reduce_mode) { reduce_rows_reference_omp(out, J, JW, W, H); return; }
 #pragma omp parallel for schedule(static, 1)
 #endif
     for (int b = 0; b < 8; ++b) {

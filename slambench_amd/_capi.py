@@ -45,6 +45,7 @@ SIGNATURES = {
     "kfh_get_position": (None, [vp, fp]),
     "kfh_get_tracked": (i32, [vp]),
     "kfh_get_integrated": (i32, [vp]),
+    "kfh_get_error": (i32, [vp]),
     "kfh_set_view_pose": (None, [vp, fp]),
     "kfh_get_model_dimensions": (None, [vp, fp]),
     "kfh_get_model_resolution": (None, [vp, u32p]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "kfh_barrier_timeouts": (u64, [vp]),
     "kfh_set_profiling": (None, [vp, u]),
     "kfh_set_profiling_stride": (None, [vp, u]),
+    "kfh_set_profiling_rotation": (None, [vp, i32]),
     "kfh_read_profile": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "kfh_read_buffer": (i64, [vp, cstr, vp, u64]),
     "kfh_write_buffer": (i64, [vp, cstr, vp, u64]),

@@ -10,7 +10,7 @@ struct Gauss5 { float g[5]; };
 // Parameter blocks that live in HBM and are rewritten by the control kernel, so that a whole frame
 // (19 ICP iterations included) is queued without the host ever reading the pose back.
 struct TrackParams { M4 view; int have_reference; int pad[3]; };       // view = K * inverse(raycastPose)
-struct IntegrateParams { M4 invTrack; M4 K; int enabled; int pad[3]; };
+struct IntegrateParams { M4 invTrack; M4 K; int enabled; float cam_bound; int pad[2]; };   // cam_bound: integrate_cam_bound()
 struct RayParams { M4 view; int enabled; int pad[3]; };
 
 struct DevState {
@@ -32,7 +32,23 @@ struct DevState {
     unsigned long long icp_level_iterations[KFH_MAX_LEVELS];   // icp_iterations by pyramid level
     unsigned tail_barrier[KFH_MAX_LEVELS];   // arrival counters of k_icp_tail's grid barrier (zero between frames)
     unsigned barrier_timeouts;               // workgroups that gave up waiting there (never, unless the device is hogged)
+    unsigned timeouts_at_track_begin;        // barrier_timeouts when the current frame's tracking began
+    unsigned failed_frames;                  // frames whose ICP loop saw a barrier time-out: pose rolled back, reported untracked
 };
+
+// Upper bound of |cam.x|, |cam.y| (cam = K * inverse(pose) * voxel centre) over the whole volume: every voxel is within
+// `far` of the camera, far = distance from the camera position to the farthest corner of [0, dim]^3, and
+// |cam.x| <= fx |pos.x| + cx |pos.z| <= (fx + cx) far.  k_integrate uses it to decide whether its batch reject is safe.
+__host__ __device__ inline float integrate_cam_bound(const M4 &pose, const float k[4], f3 dim) {
+    const float t[3] = {pose.m[0][3], pose.m[1][3], pose.m[2][3]}, d[3] = {dim.x, dim.y, dim.z};
+    float far2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        const float a = fabsf(t[i]), b = fabsf(d[i] - t[i]), m = a > b ? a : b;
+        far2 += m * m;
+    }
+    const float fx = fabsf(k[0]) + fabsf(k[2]), fy = fabsf(k[1]) + fabsf(k[3]);
+    return (fx > fy ? fx : fy) * sqrtf(far2);
+}
 
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran
 struct IcpState { M4 pose; int done[KFH_MAX_LEVELS]; int executed; int pad[3]; };
@@ -57,6 +73,7 @@ struct ControlArgs {
     int use_view_pose;   // OP_RENDER_BEGIN: 1 -> view_pose below, 0 -> current pose
     M4 view_pose;
     unsigned log_capacity;
+    float vol_dim[3];    // OP_INTEG_BEGIN: extent of the volume (integrate_cam_bound)
 };
 
 // Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_kernels.hip, "side jobs"):
@@ -89,6 +106,8 @@ struct SideWork {
 struct NextTrackBegin { DevState *state; float k[4]; unsigned frame, tracking_rate; };
 
 namespace launch {
+// first kernel launch the runtime rejected since the last call ("launch of k_x failed: ..."), or nullptr
+const char *take_launch_error();
 unsigned track_blocks(unsigned w, unsigned h);
 unsigned bilateral_tiles(unsigned W, unsigned H);
 unsigned pyramid_tiles(unsigned W, unsigned H);

@@ -11,6 +11,7 @@
 // keeping the pose on the device so the 19-iteration ICP loop never round-trips to the host.
 #include "kf_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -620,6 +621,7 @@ __global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction
 // =====================================================================================
 __device__ __forceinline__ void track_begin(DevState *__restrict__ st, bool track_frame, const float k[4]) {
     for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
+    st->timeouts_at_track_begin = __hip_atomic_load(&st->barrier_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (track_frame) {
         st->oldPose = st->pose;                                  // cpp:947
         st->track.have_reference = st->have_reference;
@@ -634,7 +636,18 @@ __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict
     if (ops & OP_TRACK_END) {
         if (track_frame) {                                           // cpp:968-969
             M4 p = st->pose;
-            const bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
+            bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
+            // a workgroup of k_icp_tail gave up at the grid barrier during this frame's loop: the sums it went on with were
+            // incomplete, so the frame counts as not tracked - old pose back, and the reduction row is marked (no inliers) so
+            // that the integration gate (cpp:991) fails the same way - and the host is told (DevState::failed_frames)
+            const unsigned now = __hip_atomic_load(&st->barrier_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (now != st->timeouts_at_track_begin) {
+                st->timeouts_at_track_begin = now;
+                st->failed_frames += 1;
+                st->reduction[28] = 0.f;
+                p = st->oldPose;
+                ok = false;
+            }
             st->pose = p;
             st->tracked = ok ? 1 : 0;
         } else {
@@ -651,6 +664,7 @@ __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict
         if (go) {
             st->integ.invTrack = inverse(p);
             st->integ.K = camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
+            st->integ.cam_bound = integrate_cam_bound(p, a.k, mk3(a.vol_dim[0], a.vol_dim[1], a.vol_dim[2]));
         }
     }
     if (ops & OP_RAY_BEGIN) {                                        // cpp:977-982
@@ -994,11 +1008,12 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 constexpr unsigned ICP_TAIL_BLOCKS = 32;
 struct IcpTailArgs {
     float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
+    unsigned long long timeout_ticks;   // of the 100 MHz wall clock (2 s; KFH_ICP_TAIL_TIMEOUT_TICKS for the error-path test)
     int final_ops;            // >= 0: the launch closes the frame's ICP loop with these control operations (k_icp_final's job)
     FrameLogEntry *log; ControlArgs ca;
 };
 
-__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, unsigned *timeouts) {
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, unsigned *timeouts, unsigned long long timeout_ticks) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();                                    // release: this workgroup's partial rows / state record
@@ -1006,7 +1021,7 @@ __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, u
         const unsigned long long t0 = wall_clock64();       // 100 MHz
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < goal) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 200000000ull) { atomicAdd(timeouts, 1u); break; }
+            if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(timeouts, 1u); break; }
         }
         __threadfence();                                    // acquire
     }
@@ -1043,7 +1058,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
             icp_track_block(sh, a, vb, t.part[it & 1]);
             __syncthreads();                                // block_reduce_store's LDS rows are reused
         }
-        if (j + 1 < t.n_its || closes) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts);
+        if (j + 1 < t.n_its || closes) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts, t.timeout_ticks);
     }
     // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
     close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
@@ -1202,8 +1217,12 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
         // per-voxel test: the very floats the reference divides, 0.1 px of margin covers the rounding of the product.
-        // batch test: interior voxels are the endpoints' interpolation plus at most IB roundings of the running sums
-        // (<= 4e-3 for |cam.x| < 1e4); with cam.z > 0.05 that moves x/z by < 0.08, hence a 0.25 px margin.
+        // batch test: interior voxels are the endpoints' interpolation plus at most IB roundings of the running sums, each
+        // <= 2^-24 |cam.x|; with cam.z > 0.05 that moves x/z by IB * 2^-24 * max|cam.x| / 0.05 pixels, which must stay below
+        // 0.2 of the 0.25 px margin.  max|cam.x| over the volume is bounded per launch (IntegrateParams::cam_bound, from the
+        // intrinsics and the camera position): where the bound fails - huge intrinsics or volumes - no batch is rejected
+        // on its end voxels and every voxel takes the reference tests.
+        const bool batch_ok = (float)IB * 5.9604645e-8f * ip->cam_bound < 0.2f * 0.05f;
         const float wlim = (float)W - 0.4f, hlim = (float)H - 0.4f;
         const float wlim_b = (float)W - 0.25f, hlim_b = (float)H - 0.25f;
         const float ptol = 2e-6f * (float)(W > H ? W : H);
@@ -1229,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                 const float cz_f = first.c.y, cz_l = last.c.y;        // cam.z
                 const bool behind = z_f < 0.00005f && z_l < 0.00005f;
                 bool outside = false;
-                if (cz_f > 0.05f && cz_l > 0.05f)
+                if (batch_ok && cz_f > 0.05f && cz_l > 0.05f)
                     outside = (outside_bits(first.b.y, first.c.x, cz_f, -0.75f, wlim_b, hlim_b) &
                                outside_bits(last.b.y, last.c.x, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
                 if (behind || outside || (dbg & 1)) continue;   // dbg: timing probes only (KFH_INTEGRATE_DBG)
@@ -1948,6 +1967,22 @@ __global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, 
 // =====================================================================================
 namespace launch {
 
+// Every launcher below notes a rejected launch (bad grid / block shape, too much LDS, ...) by kernel name; the pipeline asks
+// after each phase it queues, so a failed launch becomes KFH_ERR_HIP of that call instead of stale buffers at the next getter.
+static thread_local char g_launch_error[320] = "";
+static inline void launched(const char *kernel) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && !g_launch_error[0])
+        snprintf(g_launch_error, sizeof g_launch_error, "launch of %s failed: %s", kernel, hipGetErrorString(e));
+}
+const char *take_launch_error() {
+    static thread_local char out[320];
+    if (!g_launch_error[0]) return nullptr;
+    snprintf(out, sizeof out, "%s", g_launch_error);
+    g_launch_error[0] = 0;
+    return out;
+}
+
 static inline dim3 grid_rows(unsigned W, unsigned H) { return dim3((W + 63) / 64, (H + 3) / 4); }
 static inline dim3 block_rows() { return dim3(64, 4); }
 
@@ -2007,40 +2042,40 @@ unsigned icp_blocks(unsigned w, unsigned h) {
 
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
     const size_t n = (size_t)sx * sy * sz;
-    k_init_volume<<<2048, 256, 0, s>>>(reinterpret_cast<uint32_t *>(vol), n);
+    k_init_volume<<<2048, 256, 0, s>>>(reinterpret_cast<uint32_t *>(vol), n); launched("k_init_volume");
 }
 
 void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
                 const Gauss5 &g, float e_d, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
-    k_bilateral<true><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, e_d * e_d * 2);
+    k_bilateral<true><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, e_d * e_d * 2); launched("k_bilateral");
 }
 
 void mm2meters(float *out, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio, hipStream_t s) {
-    k_mm2meters<<<grid_rows(W, H), block_rows(), 0, s>>>(out, W, H, in, inW, ratio);
+    k_mm2meters<<<grid_rows(W, H), block_rows(), 0, s>>>(out, W, H, in, inW, ratio); launched("k_mm2meters");
 }
 
 void bilateral(float *out, const float *in, unsigned W, unsigned H, const Gauss5 &g, float e_d, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
-    k_bilateral<false><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, e_d * e_d * 2);
+    k_bilateral<false><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, e_d * e_d * 2); launched("k_bilateral");
 }
 
 void half_sample(float *out, const float *in, unsigned inW, unsigned inH, float e_d, hipStream_t s) {
     const unsigned outW = inW / 2, outH = inH / 2;
-    k_half_sample<<<grid_rows(outW, outH), block_rows(), 0, s>>>(out, in, inW, outW, outH, e_d);
+    k_half_sample<<<grid_rows(outW, outH), block_rows(), 0, s>>>(out, in, inW, outW, outH, e_d); launched("k_half_sample");
 }
 
 void depth2vertex(float4 *vertex, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s) {
-    k_depth2vertex<<<grid_rows(W, H), block_rows(), 0, s>>>(vertex, depth, W, H, invK);
+    k_depth2vertex<<<grid_rows(W, H), block_rows(), 0, s>>>(vertex, depth, W, H, invK); launched("k_depth2vertex");
 }
 
 void vertex2normal(float4 *normal, const float4 *vertex, unsigned W, unsigned H, hipStream_t s) {
-    k_vertex2normal<<<grid_rows(W, H), block_rows(), 0, s>>>(normal, vertex, W, H);
+    k_vertex2normal<<<grid_rows(W, H), block_rows(), 0, s>>>(normal, vertex, W, H); launched("k_vertex2normal");
 }
 
 void vertex_normal(float4 *vertex, float4 *normal, const float *depth, unsigned W, unsigned H, const M4 &invK, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
-    k_vertex_normal<<<grid, block, 0, s>>>(vertex, normal, depth, W, H, invK);
+    k_vertex_normal<<<grid, block, 0, s>>>(vertex, normal, depth, W, H, invK); launched("k_vertex_normal");
 }
 
 bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *const *normal, const float4 *const *stale_normal,
@@ -2057,10 +2092,10 @@ bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *
     a.W = W; a.H = H; a.e_d = e_d;
     const dim3 grid((W + PYR_T - 1) / PYR_T, (H + PYR_T - 1) / PYR_T);
     switch (n_levels) {
-    case 1: k_pyramid<1><<<grid, 256, 0, s>>>(a); break;
-    case 2: k_pyramid<2><<<grid, 256, 0, s>>>(a); break;
-    case 3: k_pyramid<3><<<grid, 256, 0, s>>>(a); break;
-    default: k_pyramid<4><<<grid, 256, 0, s>>>(a); break;
+    case 1: k_pyramid<1><<<grid, 256, 0, s>>>(a); launched("k_pyramid"); break;
+    case 2: k_pyramid<2><<<grid, 256, 0, s>>>(a); launched("k_pyramid"); break;
+    case 3: k_pyramid<3><<<grid, 256, 0, s>>>(a); launched("k_pyramid"); break;
+    default: k_pyramid<4><<<grid, 256, 0, s>>>(a); launched("k_pyramid"); break;
     }
     return true;
 }
@@ -2071,20 +2106,20 @@ void track_reduce(float *partials, int *result_map, kfh_track_data *track_out, c
                   float dist_threshold, float normal_threshold, hipStream_t s) {
     k_track_reduce<<<track_blocks(inW, inH), TR_THREADS, 0, s>>>(partials, result_map, track_out, inVertex, inNormal, inW,
                                                                inH, refVertex, refNormal, refW, refH, pose, tp, skip,
-                                                               dist_threshold, normal_threshold);
+                                                               dist_threshold, normal_threshold); launched("k_track_reduce");
 }
 
 void reduce_trackdata(float *partials, const kfh_track_data *J, unsigned JW, unsigned W, unsigned H, hipStream_t s) {
-    k_reduce_trackdata<<<track_blocks(W, H), TR_THREADS, 0, s>>>(partials, J, JW, W, H);
+    k_reduce_trackdata<<<track_blocks(W, H), TR_THREADS, 0, s>>>(partials, J, JW, W, H); launched("k_reduce_trackdata");
 }
 
 void solve(DevState *st, float *out32, const float *partials, unsigned nblocks, int level, float icp_threshold,
            int do_solve, hipStream_t s) {
-    k_solve<<<1, 1024, 0, s>>>(st, out32, partials, nblocks, level, icp_threshold, do_solve);
+    k_solve<<<1, 1024, 0, s>>>(st, out32, partials, nblocks, level, icp_threshold, do_solve); launched("k_solve");
 }
 
 void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hipStream_t s) {
-    k_control<<<1, 64, 0, s>>>(st, log, ops, a);
+    k_control<<<1, 64, 0, s>>>(st, log, ops, a); launched("k_control");
 }
 
 static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map,
@@ -2130,7 +2165,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
             a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
             extra = 1;
         }
-        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks + extra) + extra, ICP_THREADS, 0, s>>>(a, sb);
+        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks + extra) + extra, ICP_THREADS, 0, s>>>(a, sb); launched("k_icp_iter_bilateral");
         return;
     }
     if (side && side->kind == SideWork::PYRAMID && side->count) {
@@ -2152,22 +2187,22 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         }
         const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
         switch (side->n_levels) {
-        case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 3: k_icp_iter_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        default: k_icp_iter_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); launched("k_icp_iter_pyramid"); break;
+        case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); launched("k_icp_iter_pyramid"); break;
+        case 3: k_icp_iter_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); launched("k_icp_iter_pyramid"); break;
+        default: k_icp_iter_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); launched("k_icp_iter_pyramid"); break;
         }
         return;
     }
     static WaveTrace wt("KFH_ICP_TRACE");
     static const int trace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 10; }();
-    if (it == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); wt.dump(); return; } }
+    if (it == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter"); wt.dump(); return; } }
     if (side && side->kind == SideWork::RAY_ORDER) {
         a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
-        k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a);
+        k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter_order");
         return;
     }
-    k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a);
+    k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter");
 }
 
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
@@ -2181,22 +2216,24 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     IcpTailArgs t;
     t.part[0] = part0; t.part[1] = part1; t.n_its = n_its;
     t.barrier = &st->tail_barrier[level]; t.timeouts = &st->barrier_timeouts;
+    static const long long ticks_env = [] { const char *e = getenv("KFH_ICP_TAIL_TIMEOUT_TICKS"); return e ? atoll(e) : -1LL; }();
+    t.timeout_ticks = ticks_env >= 0 ? (unsigned long long)ticks_env : 200000000ull;
     t.final_ops = ca ? final_ops : -1; t.log = log;
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
-    k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t);
+    k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t); launched("k_icp_tail");
 }
 
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s) {
-    k_icp_final<<<1, ICP_THREADS, 0, s>>>(st, log, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, ops, a);
+    k_icp_final<<<1, ICP_THREADS, 0, s>>>(st, log, iters, partials_prev, n_iters, prev_level, prev_nblocks, icp_threshold, ops, a); launched("k_icp_final");
 }
 
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s) {
-    k_update_pose<<<1, 64, 0, s>>>(pose, reduction32, icp_threshold, converged);
+    k_update_pose<<<1, 64, 0, s>>>(pose, reduction32, icp_threshold, converged); launched("k_update_pose");
 }
 
 void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s) {
-    k_check_pose<<<1, 64, 0, s>>>(pose, oldPose, reduction32, W, H, thr, ok);
+    k_check_pose<<<1, 64, 0, s>>>(pose, oldPose, reduction32, W, H, thr, ok); launched("k_check_pose");
 }
 
 static long env_long(const char *name, long lo, long hi, long dflt);
@@ -2221,7 +2258,7 @@ size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz) { return (size_t)(
 
 void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
     hipMemsetAsync(flags, 0, skip_grid_bytes(sx, sy, sz), s);
-    k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3);
+    k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3); launched("k_build_skip_grid");
 }
 
 // Has the reciprocal form of a / d been verified for this divisor on this device (see k_verify_div)?  Cached; the check
@@ -2241,7 +2278,7 @@ static bool verified_divisor(float d, hipStream_t s) {
         if (hipMalloc(&dm, sizeof *dm) == hipSuccess) {
             unsigned long long h = 1;
             hipMemsetAsync(dm, 0, sizeof *dm, s);
-            k_verify_div<<<8192, 256, 0, s>>>(d, 1.0f / d, dm);
+            k_verify_div<<<8192, 256, 0, s>>>(d, 1.0f / d, dm); launched("k_verify_div");
             if (hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) ok = h == 0;
             hipFree(dm);
         }
@@ -2303,7 +2340,7 @@ static dim3 integrate_grid(unsigned sx, unsigned sy, unsigned sz, unsigned *zchu
 unsigned integrate_blocks(unsigned sx, unsigned sy, unsigned sz) { const dim3 g = integrate_grid(sx, sy, sz, nullptr); return g.x * g.y * g.z; }
 bool integrate_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_INTEGRATE_REORDER"); return !(e && e[0] == '0'); }(); return on; }
 void integrate_order(unsigned *block_order, unsigned *block_cost, unsigned n, hipStream_t s) {   // sort as a launch of its own
-    k_ray_order<<<1, 1024, 0, s>>>(block_order, block_cost, n, 1u, 1u);
+    k_ray_order<<<1, 1024, 0, s>>>(block_order, block_cost, n, 1u, 1u); launched("k_ray_order");
 }
 
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
@@ -2323,6 +2360,7 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     else if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
     else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
     else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
+    launched("k_integrate");
     wt.dump();
 }
 
@@ -2343,17 +2381,17 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group()) {
-        case 1: k_raycast<1, 1><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 1><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 1><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 1><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 1><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        case 2: k_raycast<2, 1><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        case 8: k_raycast<8, 1><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        default: k_raycast<4, 1><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         }
     } else {
         switch (ray_group()) {
-        case 1: k_raycast<1, 0><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 2: k_raycast<2, 0><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        case 8: k_raycast<8, 0><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
-        default: k_raycast<4, 0><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); break;
+        case 1: k_raycast<1, 0><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        case 2: k_raycast<2, 0><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        case 8: k_raycast<8, 0><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
+        default: k_raycast<4, 0><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         }
     }
     wt.dump();
@@ -2361,7 +2399,7 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
 
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
     const dim3 tg = ray_tile_dim(ray_group(), W, H);
-    k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y, 0u);
+    k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y, 0u); launched("k_ray_order");
 }
 void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_tile_dim(ray_group(), W, H); *tx = g.x; *ty = g.y; }
 bool ray_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_RAY_REORDER"); return !(e && e[0] == '0'); }(); return on; }
@@ -2372,16 +2410,16 @@ __global__ void k_iota(unsigned *p, unsigned n) {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
 void init_ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned n, hipStream_t s) {
-    k_iota<<<(n + 255) / 256, 256, 0, s>>>(tile_order, n);
+    k_iota<<<(n + 255) / 256, 256, 0, s>>>(tile_order, n); launched("k_iota");
     hipMemsetAsync(tile_cost, 0, (size_t)2 * n * sizeof(unsigned), s);
 }
 
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {
-    k_render_depth<<<grid_rows(W, H), block_rows(), 0, s>>>(out, depth, W, H, nearPlane, farPlane);
+    k_render_depth<<<grid_rows(W, H), block_rows(), 0, s>>>(out, depth, W, H, nearPlane, farPlane); launched("k_render_depth");
 }
 
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s) {
-    k_render_track<<<grid_rows(W, H), block_rows(), 0, s>>>(out, result_map, W, H);
+    k_render_track<<<grid_rows(W, H), block_rows(), 0, s>>>(out, result_map, W, H); launched("k_render_track");
 }
 
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
@@ -2392,17 +2430,17 @@ void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsi
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group()) {
-        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         }
     } else {
         switch (ray_group()) {
-        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
-        default: k_render_volume<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); break;
+        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        default: k_render_volume<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         }
     }
 }

@@ -64,6 +64,8 @@ struct kfh_context {
     std::vector<float *> alt_scaled;
     std::vector<float4 *> alt_inV, alt_inN;
     unsigned seen_barrier_timeouts = 0;
+    unsigned seen_failed_frames = 0;
+    int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
@@ -103,6 +105,9 @@ struct kfh_context {
     unsigned prof_mask = 0;
     unsigned prof_stride = 1, prof_tick = 0;   // queued frames: events around every prof_stride-th frame only
     bool prof_now = true;
+    bool prof_rotate = false;                  // queued frames: a sampled frame times ONE phase (the one sampled least so far)
+    int prof_only = -1;                        // that phase, or -1 = every enabled phase
+    uint64_t prof_issued[KFH_PROF_COUNT] = {};
     std::vector<hipEvent_t> prof_events[KFH_PROF_COUNT];   // start/stop pairs, in issue order
     size_t prof_used[KFH_PROF_COUNT] = {};
     double prof_ms[KFH_PROF_COUNT] = {};
@@ -147,13 +152,17 @@ static void prof_collect(kfh_context *c) {
         c->prof_used[p] = 0;
     }
 }
+static inline bool prof_wanted(const kfh_context *c, int phase) {
+    return (c->prof_mask & (1u << phase)) && c->prof_now && (c->prof_only < 0 || c->prof_only == phase);
+}
 static inline void prof_begin(kfh_context *c, int phase) {
-    if (!(c->prof_mask & (1u << phase)) || !c->prof_now) return;
+    if (!prof_wanted(c, phase)) return;
     if (c->prof_used[phase] >= 16384) prof_collect(c);
     HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
+    c->prof_issued[phase] += 1;
 }
 static inline void prof_end(kfh_context *c, int phase) {
-    if (!(c->prof_mask & (1u << phase)) || !c->prof_now) return;
+    if (!prof_wanted(c, phase)) return;
     HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
 }
 
@@ -169,6 +178,18 @@ static void fill_control(const kfh_context *c, ControlArgs &a, const float k[4],
     a.use_view_pose = c->useViewPose ? 1 : 0;
     a.view_pose = c->viewPose;
     a.log_capacity = c->log_capacity;
+    a.vol_dim[0] = c->volDim.x; a.vol_dim[1] = c->volDim.y; a.vol_dim[2] = c->volDim.z;
+}
+
+// a kernel launch the runtime rejected since the last check: named in kfh_last_error(), sticky in the context
+static bool launches_ok(kfh_context *c) {
+    if (const char *e = launch::take_launch_error()) {
+        g_last_error = e;
+        fprintf(stderr, "[kfusion-hip] %s\n", e);
+        if (c) c->error = KFH_ERR_HIP;
+        return false;
+    }
+    return true;
 }
 
 static void finish_pending_frame(kfh_context *c, const struct NextFrameWork *next);
@@ -183,6 +204,11 @@ static void refresh_mirror(kfh_context *c) {
                         "the affected frames are not to be trusted\n", c->h_state->barrier_timeouts - c->seen_barrier_timeouts);
         g_last_error = "ICP grid barrier timed out";
         c->seen_barrier_timeouts = c->h_state->barrier_timeouts;
+        c->error = KFH_ERR_BARRIER;
+    }
+    if (c->h_state->failed_frames > c->seen_failed_frames) {
+        c->seen_failed_frames = c->h_state->failed_frames;
+        c->error = KFH_ERR_BARRIER;
     }
 }
 
@@ -453,6 +479,17 @@ static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
     bool next_done = false;
     if (p.valid) {
         c->prof_now = c->prof_mask && (c->prof_tick++ % c->prof_stride) == 0;
+        c->prof_only = -1;
+        if (c->prof_now && c->prof_rotate) {
+            // one phase per sampled frame - the least sampled one among those this frame runs (host-side parts of the
+            // gates, cpp:927, 977, 994) - so that an event pair drains the queue once per sampled frame, not three times
+            const bool runs[3] = {(p.frame % p.tracking_rate) == 0, (p.frame % p.integration_rate) == 0 || p.frame <= 3, p.frame > 2};
+            const int phases[3] = {KFH_PROF_ICP, KFH_PROF_INTEGRATE, KFH_PROF_RAYCAST};
+            for (int i = 0; i < 3; ++i)
+                if (runs[i] && (c->prof_mask & (1u << phases[i])) && (c->prof_only < 0 || c->prof_issued[phases[i]] < c->prof_issued[c->prof_only]))
+                    c->prof_only = phases[i];
+            if (c->prof_only < 0) c->prof_now = false;
+        }
         next_done = enqueue_tracking(c, p.k, p.icp_threshold, p.tracking_rate, p.frame,
                                      OP_TRACK_END | OP_INTEG_BEGIN | OP_RAY_BEGIN | OP_FRAME_END, p.integration_rate, p.pyramid_ready, next);
         // the parts of the gates the host can evaluate (cpp:994, cpp:977) save the launch; the rest of the integrate
@@ -481,7 +518,7 @@ static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
 
 static inline void flush_frame(kfh_context *c) {
     if (c && c->pend.valid) finish_pending_frame(c, nullptr);
-    if (c) c->prof_now = true;   // phase calls and renders are always timed when their phase is enabled
+    if (c) { c->prof_now = true; c->prof_only = -1; }   // phase calls and renders are always timed when their phase is enabled
     if (c) c->track_begun = false;   // whatever follows may change what OP_TRACK_BEGIN reads: it will run again (it is idempotent)
 }
 
@@ -579,6 +616,15 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_result, P * sizeof(int)));
     ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float)));
     c->icp_tail_head = parse_int_list(getenv("KFH_ICP_TAIL_HEAD"));
+    {
+        // k_icp_tail synchronises its <= 32 workgroups (one CU each) with a grid barrier: they must be resident together.  Eight
+        // such launches fit the 256 CUs at once whatever else runs, so up to eight contexts per device may use it; a ninth
+        // gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could time out.
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        int live = 0;
+        for (const kfh_context *o : g_registry) live += o->device == c->device ? 1 : 0;
+        if (live >= 8) c->icp_tail_head.assign(1, 0);
+    }
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
     ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
@@ -691,6 +737,7 @@ void kfh_synchronise(kfh_context *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->kernel_timings) prof_collect(c);
     flush_pending(c);
+    launches_ok(c);
 }
 
 void kfh_synchronise_all(void) {
@@ -717,7 +764,8 @@ int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in
     }
     const uint16_t *d = stage_input(c, host_depth_mm, in_width, in_height);
     if (!d) return KFH_ERR_HIP;
-    return enqueue_preprocess(c, d, in_width, in_height);
+    const int r = enqueue_preprocess(c, d, in_width, in_height);
+    return launches_ok(c) ? r : KFH_ERR_HIP;
 }
 
 int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height) {
@@ -733,7 +781,9 @@ int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t
     flush_frame(c);
     enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END, 1);
     c->mirror_stale = true;
+    launches_ok(c);
     refresh_mirror(c);
+    if (c->error) return c->error;     // a rejected launch, or the ICP grid barrier timed out: the frame is not to be trusted
     return c->h_state->tracked;
 }
 
@@ -745,7 +795,9 @@ int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate,
     launch::control(c->d_state, c->d_log, OP_INTEG_BEGIN, a, c->stream);
     enqueue_integrate(c, mu);
     c->mirror_stale = true;
+    launches_ok(c);
     refresh_mirror(c);
+    if (c->error) return c->error;
     return c->h_state->integrated;
 }
 
@@ -756,6 +808,7 @@ int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
     fill_control(c, a, k, frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
     enqueue_raycast(c, mu);
+    if (!launches_ok(c)) return c->error;
     return 0;   // cpp:975,984: the reference always returns false
 }
 
@@ -791,7 +844,8 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
     c->pend.frame = frame; c->pend.tracking_rate = tracking_rate; c->pend.integration_rate = integration_rate;
     if (!c->pipelined) flush_frame(c);
     c->mirror_stale = true;
-    return KFH_OK;
+    launches_ok(c);
+    return c->error;   // KFH_OK, or what an EARLIER frame of this context left: queued frames report late (kfh_get_error after a sync is exact)
 }
 
 static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, uint32_t h) {
@@ -875,8 +929,15 @@ void kfh_get_position(kfh_context *c, float out3[3]) {   // kernels.h:147-154
     refresh_mirror(c);
     for (int i = 0; i < 3; ++i) out3[i] = c->h_state->pose.m[i][3] - c->initPose[i];
 }
-int kfh_get_tracked(kfh_context *c) { refresh_mirror(c); return c->h_state->tracked; }
-int kfh_get_integrated(kfh_context *c) { refresh_mirror(c); return c->h_state->integrated; }
+int kfh_get_tracked(kfh_context *c) { refresh_mirror(c); return c->error ? c->error : c->h_state->tracked; }
+int kfh_get_integrated(kfh_context *c) { refresh_mirror(c); return c->error ? c->error : c->h_state->integrated; }
+int kfh_get_error(kfh_context *c) {
+    if (!c) return KFH_ERR_ARGUMENT;
+    launches_ok(c);
+    c->mirror_stale = true;
+    refresh_mirror(c);
+    return c->error;
+}
 void kfh_set_view_pose(kfh_context *c, const float *vp) {   // kernels.h:179-184
     if (vp) { std::memcpy(&c->viewPose, vp, sizeof(M4)); c->useViewPose = true; }
     else c->useViewPose = false;
@@ -909,13 +970,17 @@ void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
     flush_frame(c);
     prof_collect(c);
     c->prof_mask = c->kernel_timings ? ((1u << KFH_PROF_COUNT) - 1u) : phase_mask;
-    for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; }
+    for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; c->prof_issued[p] = 0; }
 }
 
 void kfh_set_profiling_stride(kfh_context *c, uint32_t every_n_frames) {
     if (!c) return;
     c->prof_stride = every_n_frames ? every_n_frames : 1;
     c->prof_tick = 0;
+}
+
+void kfh_set_profiling_rotation(kfh_context *c, int32_t one_phase_per_sampled_frame) {
+    if (c) c->prof_rotate = one_phase_per_sampled_frame != 0;
 }
 
 int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]) {
@@ -1146,6 +1211,10 @@ void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], c
     IntegrateParams hp;
     std::memset(&hp, 0, sizeof hp);
     hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
+    {
+        const float k4[4] = {hp.K.m[0][0], hp.K.m[1][1], hp.K.m[0][2], hp.K.m[1][2]};
+        hp.cam_bound = integrate_cam_bound(inverse(hp.invTrack), k4, mk3(dim[0], dim[1], dim[2]));
+    }
     HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
     launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));

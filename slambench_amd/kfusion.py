@@ -69,14 +69,24 @@ class Kfusion:
             raise ValueError("Invalid ratio." if r == -1 else "kfh_preprocessing failed: %d" % r)
         return True
 
+    def _verdict(self, r, what):
+        """1 / 0 of the reference's bool returns; a negative value is a device-side failure (kfusion_hip.h, kfh_tracking)."""
+        if r < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, r, self.L.kfh_last_error().decode()))
+        return bool(r)
+
     def tracking(self, k, icp_threshold, tracking_rate, frame):
-        return bool(self.L.kfh_tracking(self.h, _capi.f32(k), icp_threshold, tracking_rate, frame))
+        return self._verdict(self.L.kfh_tracking(self.h, _capi.f32(k), icp_threshold, tracking_rate, frame), "kfh_tracking")
 
     def integration(self, k, integration_rate, mu, frame):
-        return bool(self.L.kfh_integration(self.h, _capi.f32(k), integration_rate, mu, frame))
+        return self._verdict(self.L.kfh_integration(self.h, _capi.f32(k), integration_rate, mu, frame), "kfh_integration")
 
     def raycasting(self, k, mu, frame):
-        return bool(self.L.kfh_raycasting(self.h, _capi.f32(k), mu, frame))
+        return self._verdict(self.L.kfh_raycasting(self.h, _capi.f32(k), mu, frame), "kfh_raycasting")
+
+    def get_error(self):
+        """KFH_OK (0) or the sticky error code of the context; synchronises."""
+        return int(self.L.kfh_get_error(self.h))
 
     def compute_frame(self, input_depth, input_size, k, integration_rate, tracking_rate, icp_threshold, mu, frame):
         """Kfusion::computeFrame (cpp/kernels.cpp:1048-1055); queues the frame without a host round trip."""
@@ -88,8 +98,9 @@ class Kfusion:
             ptr, is_dev = d.ctypes.data, 0
         r = self.L.kfh_compute_frame(self.h, ptr, is_dev, int(input_size[0]), int(input_size[1]), _capi.f32(k),
                                      integration_rate, tracking_rate, icp_threshold, mu, frame)
-        if r < 0:
-            raise ValueError("Invalid ratio." if r == -1 else "kfh_compute_frame failed: %d" % r)
+        if r == -1:
+            raise ValueError("Invalid ratio.")
+        self._verdict(r, "kfh_compute_frame")
 
     def _render(self, fn, *extra):
         out = np.zeros((self.H, self.W, 4), np.uint8)
@@ -129,10 +140,10 @@ class Kfusion:
         return p
 
     def get_tracked(self):
-        return bool(self.L.kfh_get_tracked(self.h))
+        return self._verdict(self.L.kfh_get_tracked(self.h), "kfh_get_tracked")
 
     def get_integrated(self):
-        return bool(self.L.kfh_get_integrated(self.h))
+        return self._verdict(self.L.kfh_get_integrated(self.h), "kfh_get_integrated")
 
     def set_view_pose(self, m=None):
         if m is None:
@@ -170,14 +181,15 @@ class Kfusion:
 
     PHASES = ("preprocess", "pyramid", "icp", "integrate", "raycast", "render_depth", "render_track", "render_volume")
 
-    def set_profiling(self, phases=(), every=1):
+    def set_profiling(self, phases=(), every=1, rotate=False):
         """Time the named phases with HIP events; `every` > 1 samples every n-th queued frame (an event record stalls
-        the queue for a few microseconds, see kfusion_hip.h)."""
+        the queue for a few microseconds, see kfusion_hip.h); `rotate` times one phase per sampled frame."""
         mask = 0
         for p in phases:
             mask |= 1 << self.PHASES.index(p)
         self.L.kfh_set_profiling(self.h, mask)
         self.L.kfh_set_profiling_stride(self.h, max(1, int(every)))
+        self.L.kfh_set_profiling_rotation(self.h, 1 if rotate else 0)
 
     def read_profile(self):
         """{phase: (total_ms, launches)} measured with HIP events on the backend's stream."""

@@ -25,6 +25,7 @@ class RankStats:
     ate_sum: float = 0.0
     ate_max: float = 0.0
     untracked: int = 0
+    failed: int = 0       # 1 = this rank hit an error: the job reports no result and every rank exits non-zero
 
 
 @dataclass
@@ -36,6 +37,7 @@ class JobStats:
     ate_mean: float
     ate_max: float
     untracked: int
+    failed: int = 0       # ranks that reported an error
 
 
 def env_rank():
@@ -48,13 +50,25 @@ def aggregate(stats: RankStats, dist=None, device="cpu") -> JobStats:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         n = max(stats.frames, 1)
         return JobStats(1, stats.frames, stats.seconds, stats.frames / stats.seconds if stats.seconds > 0 else 0.0,
-                        stats.ate_sum / n, stats.ate_max, stats.untracked)
+                        stats.ate_sum / n, stats.ate_max, stats.untracked, stats.failed)
     import torch
-    sums = torch.tensor([float(stats.frames), stats.ate_sum, float(stats.untracked)], dtype=torch.float64, device=device)
+    sums = torch.tensor([float(stats.frames), stats.ate_sum, float(stats.untracked), float(stats.failed)], dtype=torch.float64, device=device)
     maxs = torch.tensor([stats.seconds, stats.ate_max], dtype=torch.float64, device=device)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
     frames = int(round(sums[0].item()))
     seconds = float(maxs[0].item())
     return JobStats(dist.get_world_size(), frames, seconds, frames / seconds if seconds > 0 else 0.0,
-                    float(sums[1].item()) / max(frames, 1), float(maxs[1].item()), int(round(sums[2].item())))
+                    float(sums[1].item()) / max(frames, 1), float(maxs[1].item()), int(round(sums[2].item())),
+                    int(round(sums[3].item())))
+
+
+def all_ok(ok: bool, dist=None, device="cpu") -> bool:
+    """True when every rank says so (one all-reduce; a rank that failed must still call this, so that the others learn
+    of it here instead of waiting in the next barrier until the watchdog kills the job)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    import torch
+    t = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.item() == 0.0

@@ -93,3 +93,65 @@ def test_the_reference_benchmark_cpp_compiles_and_links_unmodified(tmp_path):
     # a driver that prints usage without touching the GPU: "No input found." + exit 1 (benchmark.cpp:64-68)
     r = subprocess.run([str(tmp_path / "kfusion-benchmark-refdriver")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "No input found." in r.stderr
+
+
+STUB_LIB = r"""
+#include <kfusion_hip.h>
+#include <string.h>
+/* a backend whose tracking fails on the device (ICP grid barrier time-out): what the C++ class must turn into exit(1) */
+struct kfh_context { int dummy; };
+static struct kfh_context g_ctx;
+int kfh_init(void) { return 0; }
+void kfh_clean(void) {}
+const char *kfh_last_error(void) { return "stub: ICP grid barrier timed out"; }
+kfh_context *kfh_create(uint32_t w, uint32_t h, const uint32_t r[3], const float d[3], const float p[3], const int32_t *py, int32_t n, int32_t dev, void *s) { return &g_ctx; }
+kfh_context *kfh_create_with_pose(uint32_t w, uint32_t h, const uint32_t r[3], const float d[3], const float p[16], const int32_t *py, int32_t n, int32_t dev, void *s) { return &g_ctx; }
+void kfh_destroy(kfh_context *c) {}
+void kfh_reset(kfh_context *c) {}
+void kfh_synchronise(kfh_context *c) {}
+void kfh_synchronise_all(void) {}
+int kfh_preprocessing(kfh_context *c, const uint16_t *d, uint32_t w, uint32_t h) { return 1; }
+int kfh_tracking(kfh_context *c, const float k[4], float t, uint32_t r, uint32_t f) { return KFH_ERR_BARRIER; }
+int kfh_integration(kfh_context *c, const float k[4], uint32_t r, float mu, uint32_t f) { return 1; }
+int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t f) { return 0; }
+int kfh_compute_frame(kfh_context *c, const uint16_t *d, int32_t dev, uint32_t w, uint32_t h, const float k[4], uint32_t ir, uint32_t tr, float t, float mu, uint32_t f) { return 0; }
+void kfh_render_depth(kfh_context *c, uint8_t *o, uint32_t w, uint32_t h) {}
+void kfh_render_track(kfh_context *c, uint8_t *o, uint32_t w, uint32_t h) {}
+void kfh_render_volume(kfh_context *c, uint8_t *o, uint32_t w, uint32_t h, int32_t f, int32_t r, const float k[4], float l) {}
+int kfh_dump_volume(kfh_context *c, const char *f) { return 0; }
+void kfh_get_pose(kfh_context *c, float o[16]) { memset(o, 0, 64); }
+void kfh_get_position(kfh_context *c, float o[3]) { memset(o, 0, 12); }
+int kfh_get_tracked(kfh_context *c) { return KFH_ERR_BARRIER; }
+int kfh_get_integrated(kfh_context *c) { return 0; }
+void kfh_set_view_pose(kfh_context *c, const float *v) {}
+"""
+
+FAILING_DRIVER = r"""
+#include <kernels.h>
+int main() {
+    std::vector<int> pyramid(3, 4);
+    Kfusion kfusion(make_uint2(64, 48), make_uint3(32, 32, 32), make_float3(2, 2, 2), make_float3(1, 1, 0), pyramid);
+    std::vector<uint16_t> depth(64 * 48, 1000);
+    if (!kfusion.preprocessing(depth.data(), make_uint2(64, 48))) return 3;
+    std::cout << "preprocessed" << std::endl;
+    kfusion.tracking(make_float4(60, 60, 32, 24), 1e-5f, 1, 0);
+    std::cout << "NOT REACHED" << std::endl;
+    return 0;
+}
+"""
+
+
+def test_device_side_failure_is_fatal_in_the_cpp_class(tmp_path):
+    """ADVICE r1 (k_icp_tail): a frame whose ICP grid barrier timed out must not be logged as valid.  The C ABI reports
+    KFH_ERR_BARRIER from kfh_tracking (tests/test_hip_pipeline.py forces a real one on the GPU); here a stub library
+    returns it and `class Kfusion` must print the reason and exit(1), as the reference does for its fatal errors."""
+    inc = ["-I", os.path.join(ROOT, "include", "kfusion"), "-I", os.path.join(ROOT, "include")]
+    (tmp_path / "stub.c").write_text(STUB_LIB)
+    (tmp_path / "driver.cpp").write_text(FAILING_DRIVER)
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-w"] + inc + [str(tmp_path / "stub.c"), "-o", str(tmp_path / "libkfusion_hip.so")])
+    subprocess.check_call(["g++", "-std=gnu++11"] + inc + [str(tmp_path / "driver.cpp"), "-o", str(tmp_path / "driver"), "-L", str(tmp_path),
+                           "-lkfusion_hip", "-Wl,-rpath," + str(tmp_path)])
+    r = subprocess.run([str(tmp_path / "driver")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1
+    assert "preprocessed" in r.stdout and "NOT REACHED" not in r.stdout
+    assert "Kfusion::tracking failed (-5): stub: ICP grid barrier timed out" in r.stderr

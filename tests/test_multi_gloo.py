@@ -41,6 +41,11 @@ WORKER = textwrap.dedent("""
     assert abs(job.seconds - max(gathered[0][3], gathered[1][3])) < 1e-12       # MAX over ranks
     assert abs(job.fps - job.frames / job.seconds) < 1e-9
     assert gathered[0][4] != gathered[1][4]                                     # the two ranks ran different streams
+    # a rank-local failure reaches every rank through the collectives instead of leaving the others in a barrier
+    assert multi.all_ok(True, dist) is True
+    assert multi.all_ok(rank != 1, dist) is False
+    job = multi.aggregate(multi.RankStats(n, sec, failed=1 if rank == 1 else 0), dist)
+    assert job.failed == 1
     if rank == 0:
         print(json.dumps({"fps": job.fps, "frames": job.frames, "ate_max": job.ate_max}))
     dist.destroy_process_group()
@@ -71,3 +76,4 @@ def test_single_process_aggregate():
     job = multi.aggregate(multi.RankStats(10, 2.0, 0.5, 0.2, 4))
     assert (job.world, job.frames, job.fps, job.ate_mean, job.ate_max, job.untracked) == (1, 10, 5.0, 0.05, 0.2, 4)
     assert [multi.stream_variant(r) for r in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert job.failed == 0 and multi.aggregate(multi.RankStats(10, 2.0, failed=1)).failed == 1 and multi.all_ok(False) is False

@@ -3,6 +3,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from slambench_amd import checkkernels, checkpos, perfstats, rawio, rocprof2log, synth
 
@@ -123,3 +124,36 @@ def test_rocprof_trace_to_kernel_log():
     assert lines == [("bilateralFilterKernel", 300), ("integrateKernel", 400), ("trackKernel", 1500), ("trackKernel", 500), ("raycastKernel", 50000)]
     rep = checkkernels.summarise("\n".join("%s %d" % l for l in lines))
     assert rep["track"]["count"] == 2 and rep["track"]["total"] == 2000 and rep["raycast"]["mean"] == 50000 and rep["bilateral_filter"]["count"] == 1
+
+
+def test_trajectory_table_and_real_data_hook(tmp_path, monkeypatch):
+    """Makefile:3-6 parameter lines, the Makefile's file names, and bench.py's workload loader on a `.raw` + freiburg pair."""
+    import argparse
+    import sys
+    from slambench_amd import trajectories
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    import host_inputs
+    assert [" ".join(trajectories.TRAJECTORIES[i].cli()) for i in range(4)] == [" ".join(c) for c in host_inputs.CONFIG_CASES[1:5]]
+    t2 = trajectories.TRAJECTORIES[2]
+    assert np.array_equal(t2.init_position(), np.array([0.34, 0.5, 0.24], np.float32) * np.float32(4.8))
+    assert trajectories.guess_index("/data/living_room_traj3_loop.raw") == 3 and trajectories.guess_index("livingRoom1.gt.freiburg") == 1
+    assert trajectories.guess_index("whatever.raw") == 2 and trajectories.find_dataset(str(tmp_path), 2) is None
+    s = synth.make_stream(7, 640, 480)
+    synth.write_raw(str(tmp_path / t2.raw_name()), s)
+    synth.write_freiburg(str(tmp_path / t2.gt_name()), s)
+    assert trajectories.find_dataset(str(tmp_path), 2) == (str(tmp_path / t2.raw_name()), str(tmp_path / t2.gt_name()))
+    monkeypatch.setenv("KFH_ICL_NUIM_DIR", str(tmp_path))
+    assert trajectories.find_dataset(None, 2)[0].endswith("living_room_traj2_loop.raw") and trajectories.find_dataset(None, 0) is None
+    import bench
+    args = argparse.Namespace(raw=None, gt=None, traj=None, config="cfg2")
+    wl = bench.load_workload(args, 0, 7, 640, 480)            # found through KFH_ICL_NUIM_DIR
+    assert wl.data == "icl-nuim living_room_traj2" and wl.volume_size == 4.8 and wl.k == (481.2, 480.0, 320.0, 240.0)
+    assert np.array_equal(wl.depth_mm, s.depth_mm) and len(wl.gt_rows) == 7 and wl.source.endswith(".raw")
+    with pytest.raises(SystemExit):
+        bench.load_workload(args, 0, 8, 640, 480)             # more frames than the file holds
+    monkeypatch.delenv("KFH_ICL_NUIM_DIR")
+    monkeypatch.setenv("KFUSION_SYNTH_CACHE", str(tmp_path / "cache"))
+    wl = bench.load_workload(args, 0, 3, 160, 120)
+    assert wl.data == "synthetic" and wl.depth_mm.shape == (3, 120, 160) and wl.source is None
+    wl.write_raw(str(tmp_path / "w.raw"), 2)
+    assert os.path.getsize(str(tmp_path / "w.raw")) == 2 * (16 + 160 * 120 * 5)
