@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -306,6 +307,8 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
     W, H, vres, pyramid, irate, zrate = cfg
     n_frames = args.warmup + args.steps
     prof_every = args.profile_every if args.profile_every is not None else max(1, min(8, args.steps // 10))
+    while prof_every > 1 and math.gcd(prof_every, irate) != 1:     # integrate runs on frames = 0 (mod -r): the sampled frames must meet them
+        prof_every += 1
     # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
     wl = load_workload(args, rank, n_frames + V_FRAMES, W, H)
     d_depth = torch.from_numpy(wl.depth_mm.view(np.int16)).cuda()

@@ -57,6 +57,52 @@ def test_pipeline_256_against_oracle(hip, kfmod, orc, stream):
     g.close(); o.close()
 
 
+def test_long_free_running_parity_against_the_references_own_noise_floor(hip, kfmod, orc):
+    """80 frames of BASELINE configs[1] (640x480, 256^3, -r 2) free-running through the QUEUED path against the oracle:
+    positions within 1e-4 m on every frame (observed 5.6e-6), verdict flags equal on every frame.  Per-voxel TSDF: the
+    north star's 1e-4 holds for every voxel whose integrations saw the same pixels; the rest are voxels whose projection
+    crosses a pixel boundary under a pose that differs in the sixth decimal - which no build with re-associated ICP sums can
+    avoid, the reference's own OpenMP build included (9.8e-5 of the voxels on 40 frames).  That floor is
+    measured here on the same stream - the oracle with the reference's OpenMP reduction (cpp:295-296, re-associated, thread
+    count dependent) against the oracle in serial order - and the HIP path must stay within 3x of it (observed: HIP 3.0e-4,
+    floor 1.4e-4 with 16 threads), weights differing in no more voxels than that either."""
+    n = 80
+    s = util.synth.make_stream(n, W, H)
+    k = list(s.k)
+    res = (256, 256, 256)
+
+    def off_by_more_than_1e4(a, b):
+        d = np.abs(a[..., 0].astype(np.float32) - b[..., 0].astype(np.float32)) / 32766.0
+        return float(np.mean(d > 1e-4)), float(np.mean(a[..., 1] != b[..., 1]))
+
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    orc.set_omp_reduce_mode(False)
+    o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+    worst = 0.0
+    for f in range(n):
+        g.compute_frame(s.depth_mm[f], (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        o.preprocessing(s.depth_mm[f]); to = o.tracking(k, util.ICP_THRESHOLD, 1, f); io = o.integration(k, 2, util.MU, f); o.raycasting(k, util.MU, f)
+        worst = max(worst, float(np.abs(g.get_pose() - o.get_pose()).max()))
+        assert (g.get_tracked(), g.get_integrated()) == (bool(to), bool(io)), f
+    assert worst <= 1e-4, worst
+    vo = o.buffer("volume")
+    hip_frac, hip_w = off_by_more_than_1e4(g.buffer("volume"), vo)
+    assert g.barrier_timeouts() == 0 and g.get_error() == 0
+    g.close(); o.close()
+    try:
+        orc.set_omp_reduce_mode(True)
+        r = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+        for f in range(n):
+            r.preprocessing(s.depth_mm[f]); r.tracking(k, util.ICP_THRESHOLD, 1, f); r.integration(k, 2, util.MU, f); r.raycasting(k, util.MU, f)
+        floor_frac, floor_w = off_by_more_than_1e4(r.buffer("volume"), vo)
+        r.close()
+    finally:
+        orc.set_omp_reduce_mode(False)
+    print("80 frames: max |pose - oracle| %.3g; voxels off by > 1e-4: HIP %.3g, reference-style OpenMP reduction %.3g" % (worst, hip_frac, floor_frac))
+    assert hip_frac <= max(1e-4, 3.0 * floor_frac), (hip_frac, floor_frac)
+    assert hip_w <= max(1e-4, 3.0 * max(floor_frac, floor_w)), (hip_w, floor_w)
+
+
 @pytest.mark.parametrize("res", [256, 512])
 def test_integrate_and_raycast_kernels_full_size(hip, orc, stream, res):
     """One integrate and one raycast launch at full size on identical inputs: bit-exact TSDF, vertex and normal maps."""
@@ -196,30 +242,74 @@ def test_four_level_pyramid(hip, kfmod, orc):
 
 def test_pipeline_1280x960_512_four_levels_against_oracle(hip, kfmod, orc):
     """BASELINE configs[3] at full size: 1280x960 depth, 512^3 volume, -y 10,5,4,4 (4.7 pixels per ICP thread at level 0,
-    four z-chunks of 128 in integrate, 19 200 raycast tiles - the dispatch sort runs from global memory there).  Three
-    frames of the queued path against the OpenMP oracle: the input maps of all four levels and the TSDF bit-identical
-    (frames 0-2 do not depend on the ICP sums), then the phase path and the queued path against each other."""
-    W4, H4, n = 1280, 960, 3
+    four z-chunks of 128 in integrate, 19 200 raycast tiles - the dispatch sort runs from global memory there), seven frames
+    so that frames 4-6 track against a raycast reference (cpp:950-967, 977-981).  Lock-step with the OpenMP oracle (the GPU pose
+    is overwritten with the oracle's before every phase, so every stage sees identical inputs):
+      * input maps of all four levels, TSDF and the raycast vertex / normal maps bit-identical on every frame;
+      * the ICP association of the fused kernel at 1280x960, exactly: a single-level, single-iteration context (g1 / o1, fed the
+        same poses) runs ONE level-0 association per frame - result map and the four counters equal, the float sums within
+        the re-association bound;
+      * the full four-level loop: verdicts equal, pose after ICP within 2e-5, inlier count within 1e-4 relative;
+      * the queued path (kfh_compute_frame) against the phase calls of a free-running context, bit for bit."""
+    W4, H4, n = 1280, 960, 7
     s = util.synth.make_stream(n, W4, H4)
     k = list(s.k)
     res, pyr = (512, 512, 512), (10, 5, 4, 4)
     g = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)
-    q = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)
     o = orc.OracleKfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr, omp=True)
+    g1 = kfmod.Kfusion((W4, H4), (128,) * 3, util.VOL_DIM, s.init_pos, (1,))
+    o1 = orc.OracleKfusion((W4, H4), (128,) * 3, util.VOL_DIM, s.init_pos, (1,), omp=True)
+    f_run = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)      # free-running phases ...
+    q = kfmod.Kfusion((W4, H4), res, util.VOL_DIM, s.init_pos, pyr)          # ... against the queued path
+    associated = 0
     for f in range(n):
-        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
-        assert g.tracking(k, util.ICP_THRESHOLD, 1, f) == o.tracking(k, util.ICP_THRESHOLD, 1, f)
-        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f)
-        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        pose_in = o.get_pose()
+        for x in (g, g1, o1):
+            x.set_pose(pose_in)
+        for x in (g, o, g1, o1):
+            x.preprocessing(s.depth_mm[f])
+        tg, to = g.tracking(k, util.ICP_THRESHOLD, 1, f), o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        assert tg == to, f
+        for l in range(4):
+            assert same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l)), (f, l)
+            assert same_bits(g.buffer("inputNormal%d" % l)[..., :3], o.buffer("inputNormal%d" % l)), (f, l)
+        pg, po = g.get_pose(), o.get_pose()
+        assert np.abs(pg - po).max() <= 2e-5, (f, np.abs(pg - po).max())
+        rg, ro = g.buffer("reduction"), o.buffer("reduction")[0]
+        assert abs(float(rg[28]) - float(ro[28])) <= 1e-4 * max(1.0, float(ro[28])), (f, rg[28], ro[28])
+        # one exact level-0 association at 1280x960 (the 4.7-pixels-per-thread loop of the fused ICP kernel)
+        g1.tracking(k, util.ICP_THRESHOLD, 1, f); o1.tracking(k, util.ICP_THRESHOLD, 1, f)
+        codes = o1.buffer("trackingResult")["result"]
+        assert np.array_equal(g1.buffer("trackResult"), codes), f
+        r1g, r1o = g1.buffer("reduction"), o1.buffer("reduction")[0]
+        assert np.array_equal(r1g[28:32], r1o[28:32]), (f, r1g[28:32], r1o[28:32])
+        if f >= 4:
+            assert r1o[28] > 0.5 * W4 * H4, f                 # a real case: most pixels associate
+            # float sums: the oracle adds 150 000 terms per chain serially in fp32, the GPU uses a tree - both are within
+            # ~sqrt(N) eps of the exact sum of magnitudes (tests/test_hip_kernels.py::_reduce_close uses 2e-5 at 19 200 terms)
+            from tests.test_hip_kernels import _reduce_magnitudes
+            mag = _reduce_magnitudes(o1.buffer("trackingResult"), W4, H4)
+            assert np.all(np.abs(r1g[:28].astype(np.float64) - r1o[:28]) <= 2e-4 * mag[:28] + 1e-9), f
+            associated += 1
+        for x in (g, g1, o1):
+            x.set_pose(po)
+        assert g.integration(k, 1, util.MU, f) == o.integration(k, 1, util.MU, f), f
+        g1.integration(k, 1, util.MU, f); o1.integration(k, 1, util.MU, f)
+        assert np.array_equal(g.buffer("volume"), o.buffer("volume")), "TSDF differs at frame %d" % f
+        for x in (g, o, g1, o1):
+            x.raycasting(k, util.MU, f)
+        assert same_bits(g.buffer("vertex")[..., :3], o.buffer("vertex")), f
+        assert same_bits(g.buffer("normal")[..., :3], o.buffer("normal")), f
+        assert same_bits(g1.buffer("vertex")[..., :3], o1.buffer("vertex")), f
+        f_run.preprocessing(s.depth_mm[f]); f_run.tracking(k, util.ICP_THRESHOLD, 1, f); f_run.integration(k, 1, util.MU, f); f_run.raycasting(k, util.MU, f)
         q.compute_frame(s.depth_mm[f], (W4, H4), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
-    for l in range(4):
-        assert same_bits(g.buffer("inputVertex%d" % l)[..., :3], o.buffer("inputVertex%d" % l))
-    assert np.array_equal(g.buffer("volume"), o.buffer("volume"))
-    assert same_bits(g.get_pose(), o.get_pose())                       # no reference frame yet: the pose has not moved
+    assert associated == 3 and g.get_tracked() and (o.buffer("normal")[..., 0] != -2).mean() > 0.5
     q.synchronise()
-    for name in ("volume", "vertex", "normal", "trackResult", "inputNormal0", "inputNormal3", "floatDepth"):
-        assert np.array_equal(g.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
-    g.close(); q.close(); o.close()
+    for name in ("volume", "vertex", "normal", "trackResult", "inputNormal0", "inputNormal3", "floatDepth", "pose"):
+        assert np.array_equal(f_run.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
+    assert np.abs(f_run.get_pose() - o.get_pose()).max() <= 1e-4
+    for x in (g, o, g1, o1, f_run, q):
+        x.close()
 
 
 def test_largest_volume_1024_cubed(hip, orc):

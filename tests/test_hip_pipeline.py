@@ -68,8 +68,9 @@ def test_lockstep_parity(hip, kfmod, orc):
 
 @pytest.mark.parametrize("ratio,res,pyramid", [(1, (64, 64, 64), (10, 5, 4)), (2, (48, 48, 48), (4, 3)), (1, (32, 32, 32), (6,))])
 def test_free_running_parity(hip, kfmod, orc, ratio, res, pyramid):
-    """No synchronisation between the two runs: positions must stay within the north-star tolerance (1e-4 m),
-    flags must agree and the TSDF must differ in at most a depth-discontinuity handful of voxels."""
+    """No synchronisation between the two runs: positions must stay within the north-star tolerance (1e-4 m), flags must
+    agree and at most 1e-4 of the voxels may be off by more than 1e-4 (observed on these streams: none; the reference's own
+    CPP-vs-OpenMP floor is 9.8e-5 of the voxels, BASELINE.md §2 - tests/test_hip_fullsize.py measures it on a long stream)."""
     s = util.small_stream(N_FRAMES)
     k = [v / ratio for v in s.k]
     g = _make(kfmod, s, res, pyramid, ratio)
@@ -83,7 +84,7 @@ def test_free_running_parity(hip, kfmod, orc, ratio, res, pyramid):
         assert g.raycasting(k, util.MU, f) == o.raycasting(k, util.MU, f) == False  # noqa: E712 (cpp:975,984)
         assert np.array_equal(g.render_track(), o.render_track()) or f >= 4
     assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4
-    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 2e-3
+    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 1e-4
     assert g.get_tracked() == o.get_tracked_flag and g.icp_iterations() > 0
     o.close(); g.close()
 
@@ -135,7 +136,7 @@ def test_sensor_dropout_and_saturated_frames(hip, kfmod, orc):
         g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
         assert np.abs(g.get_pose() - o.get_pose()).max() <= 1e-4, f
         q.compute_frame(depth[f], (s.width, s.height), k, 1, 1, util.ICP_THRESHOLD, util.MU, f)
-    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 2e-3
+    assert _tsdf_diff_fraction(g.buffer("volume"), o.buffer("volume")) <= 1e-4
     q.synchronise()
     pa, ta, ia = g.frame_log(N_FRAMES)
     pq, tq, iq = q.frame_log(N_FRAMES)
@@ -254,3 +255,62 @@ def test_dump_volume(hip, kfmod, orc, tmp_path):
     dumped = np.fromfile(path, dtype=np.int16)
     assert np.array_equal(dumped, g.buffer("volume")[..., 0].reshape(-1))    # cpp:1022-1026: tsdf shorts, x fastest
     g.close()
+
+
+FORCED_TIMEOUT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from slambench_amd import kfusion, synth
+s = synth.make_stream(6, 160, 120)
+k = list(s.k)
+g = kfusion.Kfusion((160, 120), (64, 64, 64), (4.8,) * 3, s.init_pos)
+pose0 = g.get_pose()
+raised = None
+for f in range(6):
+    g.preprocessing(s.depth_mm[f])
+    try:
+        g.tracking(k, 0.0, 1, f)          # threshold 0: no level ever converges, so the tail launch runs its iterations
+    except RuntimeError as e:
+        raised = (f, str(e))
+        break
+    g.integration(k, 1, 0.1, f); g.raycasting(k, 0.1, f)
+assert raised is not None, "a barrier that cannot be passed in time must fail the frame"
+assert "(-5)" in raised[1], raised
+assert g.get_error() == -5 and g.barrier_timeouts() > 0
+state_pose = g.buffer("pose")
+old = g.buffer("oldPose")
+assert np.array_equal(state_pose, old), "the pose of a failed frame is rolled back"
+try:
+    g.get_tracked()
+except RuntimeError:
+    pass
+else:
+    raise AssertionError("the verdict getter must not report a failed frame as valid")
+print("FAILED_FRAME", raised[0])
+"""
+
+
+def test_barrier_timeout_fails_the_frame(hip, tmp_path):
+    """a workgroup of k_icp_tail that gives up at the grid barrier carried on with stale sums and the frame was still
+    logged as valid.  With the time-out forced to zero (KFH_ICP_TAIL_TIMEOUT_TICKS=0, own process: the knob is read once) the
+    frame must fail everywhere: pose rolled back on the device, KFH_ERR_BARRIER from kfh_tracking and the getters, sticky
+    kfh_get_error, and the drop-in driver exits non-zero."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "forced.py"
+    script.write_text(FORCED_TIMEOUT % root)
+    env = dict(os.environ, KFH_ICP_TAIL_TIMEOUT_TICKS="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "FAILED_FRAME" in r.stdout and "timed out at the ICP grid barrier" in r.stderr
+    from slambench_amd import build, synth
+    s = synth.make_stream(6, 160, 120)
+    raw = str(tmp_path / "s.raw")
+    synth.write_raw(raw, s)
+    cmd = [build.BENCH_BIN, "-i", raw, "-s", "4.8", "-p", "0.34,0.5,0.24", "-k", ",".join("%g" % v for v in s.k), "-v", "64", "-l", "0",
+           "-o", str(tmp_path / "x.log")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Kfusion::tracking failed (-5)" in r.stderr, (r.returncode, r.stderr[-2000:])
