@@ -2,7 +2,7 @@
 # usage: profiles/sweep.sh "<ENV=VAL ...>" ...   — runs the short bench once per environment setting
 for envs in "$@"; do
   echo "== $envs"
-  env $envs python bench.py --steps 100 --no-cpu-baseline --no-total 2>/dev/null | python -c "
+  env $envs python bench.py --steps 100 --no-cpu-baseline --no-total --no-host-buffers 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']; o=d['roofline_other']

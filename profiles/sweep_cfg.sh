@@ -2,7 +2,7 @@
 # usage: profiles/sweep_cfg.sh <config> "<ENV=VAL ...>" ...   — short bench of another configuration, one line per setting
 cfg=$1; shift
 for envs in "$@"; do
-  env $envs python bench.py --config $cfg --steps 100 --no-cpu-baseline --no-total 2>/dev/null | python -c "
+  env $envs python bench.py --config $cfg --steps 100 --no-cpu-baseline --no-total --no-host-buffers 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

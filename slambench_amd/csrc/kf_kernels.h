@@ -10,7 +10,7 @@ struct Gauss5 { float g[5]; };
 // Parameter blocks that live in HBM and are rewritten by the control kernel, so that a whole frame
 // (19 ICP iterations included) is queued without the host ever reading the pose back.
 struct TrackParams { M4 view; int have_reference; int pad[3]; };       // view = K * inverse(raycastPose)
-struct IntegrateParams { M4 invTrack; M4 K; int enabled; float cam_bound; int pad[2]; };   // cam_bound: integrate_cam_bound()
+struct IntegrateParams { M4 invTrack; M4 K; int enabled; float cam_bound, far_bound; int pad; };   // bounds: integrate_bounds()
 struct RayParams { M4 view; int enabled; int pad[3]; };
 
 struct DevState {
@@ -36,18 +36,21 @@ struct DevState {
     unsigned failed_frames;                  // frames whose ICP loop saw a barrier time-out: pose rolled back, reported untracked
 };
 
-// Upper bound of |cam.x|, |cam.y| (cam = K * inverse(pose) * voxel centre) over the whole volume: every voxel is within
-// `far` of the camera, far = distance from the camera position to the farthest corner of [0, dim]^3, and
-// |cam.x| <= fx |pos.x| + cx |pos.z| <= (fx + cx) far.  k_integrate uses it to decide whether its batch reject is safe.
-__host__ __device__ inline float integrate_cam_bound(const M4 &pose, const float k[4], f3 dim) {
+// Upper bounds over the whole volume of |pos.*| (pos = inverse(pose) * voxel centre: every voxel is within `far` of the
+// camera, far = distance from the camera position to the farthest corner of [0, dim]^3, slightly inflated) and of
+// |cam.x|, |cam.y| (cam = K * pos: |cam.x| <= fx |pos.x| + cx |pos.z| <= (fx + cx) far).  k_integrate derives from them how far
+// a marched state (n rounded additions) can be from the exact line, i.e. which of its shortcuts are safe for this launch.
+__host__ __device__ inline void integrate_bounds(const M4 &pose, const float k[4], f3 dim, float *cam_bound, float *far_bound) {
     const float t[3] = {pose.m[0][3], pose.m[1][3], pose.m[2][3]}, d[3] = {dim.x, dim.y, dim.z};
     float far2 = 0.f;
     for (int i = 0; i < 3; ++i) {
         const float a = fabsf(t[i]), b = fabsf(d[i] - t[i]), m = a > b ? a : b;
         far2 += m * m;
     }
+    const float far = sqrtf(far2) * 1.001f + 1e-3f;
     const float fx = fabsf(k[0]) + fabsf(k[2]), fy = fabsf(k[1]) + fabsf(k[3]);
-    return (fx > fy ? fx : fy) * sqrtf(far2);
+    *far_bound = far;
+    *cam_bound = (fx > fy ? fx : fy) * far;
 }
 
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran

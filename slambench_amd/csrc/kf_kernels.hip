@@ -664,7 +664,7 @@ __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict
         if (go) {
             st->integ.invTrack = inverse(p);
             st->integ.K = camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
-            st->integ.cam_bound = integrate_cam_bound(p, a.k, mk3(a.vol_dim[0], a.vol_dim[1], a.vol_dim[2]));
+            integrate_bounds(p, a.k, mk3(a.vol_dim[0], a.vol_dim[1], a.vol_dim[2]), &st->integ.cam_bound, &st->integ.far_bound);
         }
     }
     if (ops & OP_RAY_BEGIN) {                                        // cpp:977-982
@@ -1212,6 +1212,36 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         const v2f da = (v2f){delta.x, delta.y}, db = (v2f){delta.z, cameraDelta.x}, dc = (v2f){cameraDelta.y, cameraDelta.z};
         const unsigned z0 = vbz * zchunk;
         const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
+        // Whole-chunk reject BEFORE the replay.  The marched state of voxel z is the exact line pos0 + z * delta plus at
+        // most z rounded additions, each off by <= 2^-24 of the value: |error| <= E = (sz + 4) 2^-24 cam_bound for cam.x / cam.y
+        // and <= Ez = (sz + 4) 2^-24 far_bound for cam.z = pos.z.  The reference skips a voxel when pos.z < 1e-4 or the pixel
+        // cam.x / cam.z + 0.5 falls outside [0, W-1] x [0, H-1] (cpp:647-653); "outside on the left" is cam.x + 0.5 cam.z < 0
+        // for cam.z > 0, a LINEAR condition, so if the un-marched end points of the chunk satisfy it with E + 0.5 Ez to
+        // spare (plus a quarter pixel for the rounding of the reference's own division), every marched voxel in between
+        // does: the chunk updates nothing and the thread leaves without replaying its z0 additions.  Four of five chunks
+        // lie outside the frustum; what remains pays the replay, which is what lets the chunks be short (see integrate_grid).
+        bool chunk_out = false;
+        if (!(dbg & 8)) {
+            const float zf = (float)z0, zl = (float)(z1 - 1);
+            const float n_err = (float)(sz + 4) * 5.9604645e-8f;
+            const float E = n_err * ip->cam_bound, Ez = n_err * ip->far_bound;
+            const float pzf = __builtin_fmaf(zf, delta.z, pos0.z), pzl = __builtin_fmaf(zl, delta.z, pos0.z);
+            const float cxf = __builtin_fmaf(zf, cameraDelta.x, cam0.x), cxl = __builtin_fmaf(zl, cameraDelta.x, cam0.x);
+            const float cyf = __builtin_fmaf(zf, cameraDelta.y, cam0.y), cyl = __builtin_fmaf(zl, cameraDelta.y, cam0.y);
+            const float czf = __builtin_fmaf(zf, cameraDelta.z, cam0.z), czl = __builtin_fmaf(zl, cameraDelta.z, cam0.z);
+            const bool behind = pzf < -Ez - 1e-3f && pzl < -Ez - 1e-3f;           // every marched pos.z < 1e-4
+            if (czf > Ez + 1e-3f && czl > Ez + 1e-3f) {                            // every marched cam.z > 0
+                const float wq = (float)W - 0.25f, hq = (float)H - 0.25f;         // right / bottom: pixel > size - 1, i.e. c > (size - 0.5) z
+                const float el = E + 0.75f * Ez, er = E + wq * Ez, eb = E + hq * Ez;
+                const bool left = cxf + 0.75f * czf < -el && cxl + 0.75f * czl < -el;
+                const bool right = cxf - wq * czf > er && cxl - wq * czl > er;
+                const bool top = cyf + 0.75f * czf < -el && cyl + 0.75f * czl < -el;
+                const bool bottom = cyf - hq * czf > eb && cyl - hq * czl > eb;
+                chunk_out = left || right || top || bottom;
+            }
+            chunk_out = chunk_out || behind;
+        }
+        if (!chunk_out)
         for (unsigned z = 0; z < z0; ++z) { S.a += da; S.b += db; S.c += dc; }
         const size_t plane = (size_t)sx * sy;
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
@@ -1226,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         const float wlim = (float)W - 0.4f, hlim = (float)H - 0.4f;
         const float wlim_b = (float)W - 0.25f, hlim_b = (float)H - 0.25f;
         const float ptol = 2e-6f * (float)(W > H ? W : H);
-        for (unsigned zb = z0; zb < z1; zb += IB, cell += (size_t)IB * plane) {
+        for (unsigned zb = chunk_out ? z1 : z0; zb < z1; zb += IB, cell += (size_t)IB * plane) {
             const unsigned nb = (z1 - zb) < (unsigned)IB ? (z1 - zb) : (unsigned)IB;
             const ColumnState first = S;
             ColumnState last;
@@ -2347,7 +2377,12 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
                unsigned *block_order, unsigned *block_cost, hipStream_t s) {
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
-    static const int dbg = (int)env_long("KFH_INTEGRATE_DBG", 0, 7, 0);
+    // timing probes (results are wrong with them): 1 every batch rejected, 2 stop after the projection pass, 4 stop after the depth
+    // classification, 8 no whole-chunk reject; KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
+    static const int dbg_env = (int)env_long("KFH_INTEGRATE_DBG", 0, 15, 0);
+    static const long dbg_from = env_long("KFH_INTEGRATE_DBG_FROM", 0, 1000000, 0);
+    static long n_launch = 0;
+    const int dbg = (dbg_env && n_launch++ >= dbg_from) ? dbg_env : 0;
     unsigned zchunk;
     const dim3 grid = integrate_grid(sx, sy, sz, &zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);

@@ -1213,7 +1213,7 @@ void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], c
     hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
     {
         const float k4[4] = {hp.K.m[0][0], hp.K.m[1][1], hp.K.m[0][2], hp.K.m[1][2]};
-        hp.cam_bound = integrate_cam_bound(inverse(hp.invTrack), k4, mk3(dim[0], dim[1], dim[2]));
+        integrate_bounds(inverse(hp.invTrack), k4, mk3(dim[0], dim[1], dim[2]), &hp.cam_bound, &hp.far_bound);
     }
     HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
     launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, nullptr, nullptr, s);
