@@ -157,3 +157,40 @@ def test_trajectory_table_and_real_data_hook(tmp_path, monkeypatch):
     assert wl.data == "synthetic" and wl.depth_mm.shape == (3, 120, 160) and wl.source is None
     wl.write_raw(str(tmp_path / "w.raw"), 2)
     assert os.path.getsize(str(tmp_path / "w.raw")) == 2 * (16 + 160 * 120 * 5)
+
+
+def test_cpu_sibling_drivers_run_baseline_config0(tmp_path):
+    """BASELINE configs[0] (`-c 2 -v 128,128,128 -r 1`, "CPU ref, plumbing") on the CPU siblings of kfusion-benchmark-hip: the same
+    driver source over the CPU restatement (oracle/orc_kfh_shim.cpp), serial and OpenMP - as the reference builds
+    kfusion-benchmark-{cpp,openmp} from one benchmark.cpp.  Same log format, same positions from both (the OpenMP build is
+    bit-identical by default), and the python binding of the restatement agrees to the printed digit."""
+    from oracle import orc
+    orc.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 7
+    s = synth.make_stream(n, 320, 240)
+    raw = str(tmp_path / "qvga.raw")
+    synth.write_raw(raw, s)
+    k = ",".join("%g" % v for v in s.k)
+    logs = {}
+    for name in ("cpp", "openmp"):
+        exe = os.path.join(root, "oracle", "kfusion-benchmark-" + name)
+        log, vol = str(tmp_path / (name + ".log")), str(tmp_path / (name + ".vol"))
+        r = subprocess.run([exe, "-i", raw, "-s", "4.8", "-p", "0.34,0.5,0.24", "-z", "4", "-c", "2", "-v", "128,128,128", "-r", "1", "-k", k,
+                            "-o", log, "-d", vol], capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "input Size is = 320,240" in r.stderr
+        logs[name] = checkpos.parse_log(open(log).read())["columns"]
+        assert len(logs[name]["frame"]) == n and os.path.getsize(vol) == 128 ** 3 * 2
+    for col in ("X", "Y", "Z", "tracked", "integrated"):
+        assert logs["cpp"][col] == logs["openmp"][col], col
+    assert logs["cpp"]["tracked"] == [0.0] * 4 + [1.0] * (n - 4) and min(logs["cpp"]["computation"]) > 0
+    assert open(str(tmp_path / "cpp.vol"), "rb").read() == open(str(tmp_path / "openmp.vol"), "rb").read()
+    init = np.array([0.34, 0.5, 0.24], np.float32) * np.float32(4.8)
+    o = orc.OracleKfusion((160, 120), (128,) * 3, (4.8,) * 3, init)
+    kk = [float(np.float32(v) / np.float32(2)) for v in np.array(s.k, np.float32)]
+    for f in range(n):
+        assert np.allclose(o.get_position(), (logs["cpp"]["X"][f], logs["cpp"]["Y"][f], logs["cpp"]["Z"][f]), atol=5.1e-7), f
+        o.preprocessing(s.depth_mm[f]); o.tracking(kk, 1e-5, 1, f); o.integration(kk, 1, 0.1, f); o.raycasting(kk, 0.1, f)
+    assert np.array_equal(np.fromfile(str(tmp_path / "cpp.vol"), np.int16), o.buffer("volume")[..., 0].reshape(-1))
+    o.close()
