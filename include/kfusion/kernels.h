@@ -123,6 +123,9 @@ public:
     void dumpVolume(const char *filename) {
         if (kfh_dump_volume(ctx_, filename) == KFH_ERR_IO) std::exit(1);   // cpp/kernels.cpp:1017-1020
     }
+    // The three renders are QUEUED: `out` holds the image after the next synchroniseDevices() (every tock() of benchmark.cpp
+    // calls it; the reference's OpenCL backend reads its render targets back the same way, opencl/kernels.cpp:420).  The
+    // buffer must stay valid until then; a Kfusion that is destroyed first drops the copy instead of writing to it.
     void renderVolume(uchar4 *out, const uint2 outputSize, int frame, int rate, float4 k, float mu) {
         float kk[4];
         k4(k, kk);
