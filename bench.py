@@ -187,7 +187,7 @@ def timed_run(make_leg, torch, dist, multi, n_warm, n_steps, prof_every, coll_de
     return elapsed, leg, err
 
 
-def cpu_baseline(wl, cfg, budget_s, max_frames):
+def cpu_baseline(wl, cfg, budget_s, max_frames, min_frames=8):
     """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only); then V of
     SURVEY §8(d) - the distinct voxels one raycast samples - counted by the oracle on the V_FRAMES frames that follow the prefix."""
     from oracle import orc
@@ -210,7 +210,7 @@ def cpu_baseline(wl, cfg, budget_s, max_frames):
 
     n, spent = 0, 0.0
     timed_max = max(1, min(max_frames, wl.depth_mm.shape[0]) - V_FRAMES)
-    while n < timed_max and (spent < budget_s or n < 8):
+    while n < timed_max and (spent < budget_s or n < min_frames):
         t = time.perf_counter()
         frame(n)
         spent += time.perf_counter() - t
@@ -363,6 +363,10 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
     cpu, v_distinct = (None, None)
     if not args.no_cpu_baseline and world == 1:
         cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, n_frames + V_FRAMES)
+    elif not args.no_cpu_baseline:
+        # N > 1: no CPU baseline (rank 0 at N = 1 only), but raycast's algorithmic bytes still need V: the oracle runs just far
+        # enough to have a surface to cast at (6 frames) and counts on the two that follow
+        _, v_distinct = cpu_baseline(wl, cfg, 0.0, min(n_frames + V_FRAMES, 6 + V_FRAMES), min_frames=6)
     host = None
     if not args.no_host_buffers and world == 1:
         del d_depth
