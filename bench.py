@@ -411,15 +411,17 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n,
                       "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg), **detail}
-    # The ICP loop of a frame (k_icp_iter* launches, k_icp_tail for the late iterations of a level, k_icp_final): 48 bytes per associated pixel (two float4 input
-    # maps, a 32-byte gather from the reference maps) for every EXECUTED iteration, plus - on the queued-frame path - the
+    # The ICP loop of a frame (k_icp_iter* launches, k_icp_tail for the late iterations of a level, k_icp_final): 48 + 4 bytes per associated pixel
+    # for every EXECUTED iteration (below), plus - on the queued-frame path - the
     # next frame's bilateral filter (2P in, 8P out) and pyramid (4P in, 36 bytes per pixel of every level out) that ride
     # on it.  One "launch" of this entry is one frame's loop.
     ms, n = prof["icp"]
     if n:
         levels = len(pyramid)
         px = [(W >> l) * (H >> l) for l in range(levels)]
-        alg_icp = 48.0 * sum(icp_by_level[l] * px[l] for l in range(levels)) / max(1, n_frames)
+        # SURVEY §8(d), fused track + reduce: 48 bytes per associated pixel (two float4 input maps, a 32-byte gather from the
+        # reference maps) + 4 for the result map the launch keeps for renderTrack, per EXECUTED iteration
+        alg_icp = 52.0 * sum(icp_by_level[l] * px[l] for l in range(levels)) / max(1, n_frames)
         alg_pre = 10.0 * P + 4.0 * P + 36.0 * sum(px)
         alg = alg_icp + alg_pre
         avg_s = ms / n * 1e-3
