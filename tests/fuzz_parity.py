@@ -58,6 +58,60 @@ def run(hip, orc, seed=7, trials=12, verbose=False):
     return bad
 
 
+def run_extreme(hip, orc, seed=3, trials=12, verbose=False):
+    """integrateKernel where its shortcuts are at their limits: arbitrary rotations (the volume seen upside down, edge-on, from a
+    corner), cameras inside, on the faces of and outside the volume, intrinsics scaled up to 16x (the rounding bound of the
+    whole-chunk / batch rejects fails and every voxel must take the reference tests), depth images that are planes, noise or
+    mostly holes - two integrations each, bit for bit against the oracle."""
+    rng = np.random.default_rng(seed)
+    dev = Dev()
+    bad = []
+    for trial in range(trials):
+        W, H = [(160, 120), (96, 72), (208, 160)][trial % 3]
+        res = tuple(int(v) for v in rng.choice([32, 48, 64, 96, 128], 3))
+        dim = tuple(float(v) for v in rng.uniform(1.0, 6.0, 3))
+        scale = float(rng.choice([1.0, 1.0, 4.0, 16.0]))
+        k = [481.2 * W / 640 * scale, 480.0 * H / 480 * scale, W / 2.0 + rng.uniform(-20, 20), H / 2.0 + rng.uniform(-20, 20)]
+        K = orc.camera_matrix(k)
+        vol = orc.init_volume(res, omp=True)
+        d_vol = dev.put(vol.copy())
+        for f in range(2):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            a, b, c, d = q
+            R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                          [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                          [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+            pose = np.eye(4, dtype=np.float32)
+            pose[:3, :3] = R.astype(np.float32)
+            where = trial % 4
+            lo, hi = (-0.3, 1.3) if where == 0 else ((0.2, 0.8) if where == 1 else ((-1.0, 0.0) if where == 2 else (0.0, 1.0)))
+            pose[:3, 3] = (rng.uniform(lo, hi, 3) * np.array(dim)).astype(np.float32)
+            if where == 3:
+                pose[int(rng.integers(0, 3)), 3] = 0.0            # exactly on a face of the volume
+            kind = (trial + f) % 3
+            if kind == 0:
+                depth = np.full((H, W), rng.uniform(0.4, 3.0), np.float32) + rng.normal(0, 0.02, (H, W)).astype(np.float32)
+            elif kind == 1:
+                depth = rng.uniform(0.0, 5.0, (H, W)).astype(np.float32)
+            else:
+                depth = np.where(rng.random((H, W)) < 0.7, 0.0, rng.uniform(0.3, 4.0, (H, W))).astype(np.float32)
+            depth = np.ascontiguousarray(np.maximum(depth, 0.0), np.float32)
+            inv_track = orc.inverse(pose)
+            orc.integrate(vol, dim, depth, inv_track, K, omp=True)
+            hip.kfh_k_integrate(d_vol.data_ptr(), u32(res), f32(dim), dev.put(depth).data_ptr(), W, H, m16(inv_track), m16(K), 0.1,
+                                100.0, dev.stream)
+        ok = np.array_equal(dev.get(d_vol), vol)
+        if verbose:
+            print("extreme trial %3d  %dx%d  res %s  dim %s  k-scale %g  camera %s  updated %.3f  %s" % (
+                trial, W, H, res, tuple(round(v, 2) for v in dim), scale, ["around", "inside", "outside", "on a face"][trial % 4],
+                float((vol[..., 1] > 0).mean()), ok))
+        if not ok:
+            bad.append((trial, res, dim, scale))
+        dev.clear()
+    return bad
+
+
 def run_track(hip, orc, seed=5, trials=8, verbose=False):
     """The ICP association kernel (trackKernel, cpp:497-560) on the maps of a short oracle run, with the pose to test
     perturbed at random (up to 3 degrees / 4 cm: pixels fall off the image, distance and normal tests flip): result codes,
@@ -156,5 +210,6 @@ if __name__ == "__main__":
     failures = run(_capi.lib(), _orc, seed, trials, verbose=True)
     failures += run_maps(_kf, _orc, seed, max(4, trials // 4), verbose=True)
     failures += run_track(_capi.lib(), _orc, seed, max(4, trials // 8), verbose=True)
+    failures += run_extreme(_capi.lib(), _orc, seed, max(12, trials // 2), verbose=True)
     print("trials %d, mismatches %d" % (trials, len(failures)))
     sys.exit(1 if failures else 0)
