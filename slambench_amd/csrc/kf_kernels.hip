@@ -11,6 +11,7 @@
 // keeping the pose on the device so the 19-iteration ICP loop never round-trips to the host.
 #include "kf_kernels.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -632,6 +633,7 @@ __device__ __forceinline__ void track_begin(DevState *__restrict__ st, bool trac
 
 __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, const ControlArgs &a) {
     const bool track_frame = (a.frame % a.tracking_rate) == 0;   // cpp:927
+    if (a.clear_integrated) { st->integrated = 0; st->integ.enabled = 0; }
     if (ops & OP_TRACK_BEGIN) track_begin(st, track_frame, a.k);
     if (ops & OP_TRACK_END) {
         if (track_frame) {                                           // cpp:968-969
@@ -2381,8 +2383,8 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     // classification, 8 no whole-chunk reject; KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
     static const int dbg_env = (int)env_long("KFH_INTEGRATE_DBG", 0, 15, 0);
     static const long dbg_from = env_long("KFH_INTEGRATE_DBG_FROM", 0, 1000000, 0);
-    static long n_launch = 0;
-    const int dbg = (dbg_env && n_launch++ >= dbg_from) ? dbg_env : 0;
+    static std::atomic<long> n_launch{0};
+    const int dbg = (dbg_env && n_launch.fetch_add(1) >= dbg_from) ? dbg_env : 0;
     unsigned zchunk;
     const dim3 grid = integrate_grid(sx, sy, sz, &zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);

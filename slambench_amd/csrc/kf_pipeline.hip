@@ -65,6 +65,7 @@ struct kfh_context {
     std::vector<float4 *> alt_inV, alt_inN;
     unsigned seen_barrier_timeouts = 0;
     unsigned seen_failed_frames = 0;
+    bool clear_integrated = false;     // kfh_integration decided "not integrated" on the host: the device flag follows with the next control operation
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
@@ -166,7 +167,7 @@ static inline void prof_end(kfh_context *c, int phase) {
     HIP_TRY(hipEventRecord(prof_event(c, phase), c->stream));
 }
 
-static void fill_control(const kfh_context *c, ControlArgs &a, const float k[4], unsigned frame, unsigned tracking_rate,
+static void fill_control(kfh_context *c, ControlArgs &a, const float k[4], unsigned frame, unsigned tracking_rate,
                          unsigned integration_rate) {
     std::memset(&a, 0, sizeof a);
     if (k) for (int i = 0; i < 4; ++i) a.k[i] = k[i];
@@ -179,6 +180,8 @@ static void fill_control(const kfh_context *c, ControlArgs &a, const float k[4],
     a.view_pose = c->viewPose;
     a.log_capacity = c->log_capacity;
     a.vol_dim[0] = c->volDim.x; a.vol_dim[1] = c->volDim.y; a.vol_dim[2] = c->volDim.z;
+    a.clear_integrated = c->clear_integrated ? 1 : 0;
+    c->clear_integrated = false;       // (every caller launches the operation it fills in)
 }
 
 // a kernel launch the runtime rejected since the last check: named in kfh_last_error(), sticky in the context
@@ -741,18 +744,17 @@ void kfh_synchronise(kfh_context *c) {
 }
 
 void kfh_synchronise_all(void) {
-    std::vector<kfh_context *> live;
-    {
-        std::lock_guard<std::mutex> lk(g_registry_mu);
-        live = g_registry;
-    }
+    // the registry stays locked while its contexts are waited for: a context cannot be destroyed (kfh_destroy takes the same
+    // lock to leave the registry) under the feet of this loop
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    if (g_registry.empty()) return;
     int before = 0;
     hipGetDevice(&before);
-    for (kfh_context *c : live) {
+    for (kfh_context *c : g_registry) {
         hipSetDevice(c->device);
         kfh_synchronise(c);
     }
-    if (!live.empty()) hipSetDevice(before);
+    hipSetDevice(before);
 }
 
 int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) {
@@ -790,6 +792,14 @@ int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t
 int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate, float mu, uint32_t frame) {
     if (!c || !k || !integration_rate) return KFH_ERR_ARGUMENT;
     flush_frame(c);
+    if ((frame % integration_rate) != 0 && frame > 3) {
+        // cpp:994: off the integration rate and past frame 3 the frame is not integrated whatever tracking said, and the pose
+        // roll-back of a bad track (cpp:991) has been applied by tracking() already: nothing to launch, nothing to wait for.
+        // The device flags follow with the next control operation (raycasting's), the host's view at once.
+        c->clear_integrated = true;
+        c->h_state->integrated = 0;
+        return c->error ? c->error : 0;
+    }
     ControlArgs a;
     fill_control(c, a, k, frame, 1, integration_rate);
     launch::control(c->d_state, c->d_log, OP_INTEG_BEGIN, a, c->stream);
@@ -808,6 +818,7 @@ int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
     fill_control(c, a, k, frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RAY_BEGIN | OP_FRAME_END, a, c->stream);
     enqueue_raycast(c, mu);
+    c->mirror_stale = true;
     if (!launches_ok(c)) return c->error;
     return 0;   // cpp:975,984: the reference always returns false
 }
@@ -930,7 +941,11 @@ void kfh_get_position(kfh_context *c, float out3[3]) {   // kernels.h:147-154
     for (int i = 0; i < 3; ++i) out3[i] = c->h_state->pose.m[i][3] - c->initPose[i];
 }
 int kfh_get_tracked(kfh_context *c) { refresh_mirror(c); return c->error ? c->error : c->h_state->tracked; }
-int kfh_get_integrated(kfh_context *c) { refresh_mirror(c); return c->error ? c->error : c->h_state->integrated; }
+int kfh_get_integrated(kfh_context *c) {
+    refresh_mirror(c);
+    if (c->error) return c->error;
+    return c->clear_integrated ? 0 : c->h_state->integrated;
+}
 int kfh_get_error(kfh_context *c) {
     if (!c) return KFH_ERR_ARGUMENT;
     launches_ok(c);
