@@ -194,3 +194,40 @@ def test_cpu_sibling_drivers_run_baseline_config0(tmp_path):
         o.preprocessing(s.depth_mm[f]); o.tracking(kk, 1e-5, 1, f); o.integration(kk, 1, 0.1, f); o.raycasting(kk, 0.1, f)
     assert np.array_equal(np.fromfile(str(tmp_path / "cpp.vol"), np.int16), o.buffer("volume")[..., 0].reshape(-1))
     o.close()
+
+
+def test_bench_timed_run_reports_a_failing_rank(capsys):
+    """bench.py's timed region on fakes (no GPU): a leg that cannot be set up ends the run through the collective check instead
+    of leaving other ranks in a barrier; a leg that fails inside the timed region hands the error back; a good leg is stepped
+    warm-up + steps times and synchronised on both sides."""
+    import types
+    import bench
+    from slambench_amd import multi
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(synchronize=lambda: None))
+
+    class Leg:
+        with_renders = False
+
+        def __init__(self, fail_at=None):
+            self.steps, self.syncs, self.fail_at = [], 0, fail_at
+            self.kf = types.SimpleNamespace(set_profiling=lambda *a, **k: None)
+
+        def step(self, f):
+            if f == self.fail_at:
+                raise RuntimeError("boom at %d" % f)
+            self.steps.append(f)
+
+        def sync(self):
+            self.syncs += 1
+
+    def broken():
+        raise RuntimeError("no device")
+
+    with pytest.raises(SystemExit):
+        bench.timed_run(broken, fake_torch, None, multi, 2, 3, 1, "cpu")
+    assert "failed before the timed region" in capsys.readouterr().err
+    elapsed, leg, err = bench.timed_run(lambda: Leg(), fake_torch, None, multi, 2, 3, 1, "cpu")
+    assert err is None and leg.steps == [0, 1, 2, 3, 4] and leg.syncs == 2 and elapsed >= 0
+    elapsed, leg, err = bench.timed_run(lambda: Leg(fail_at=3), fake_torch, None, multi, 2, 3, 1, "cpu")
+    assert isinstance(err, RuntimeError) and leg.steps == [0, 1, 2]
+    assert bench.icp_launches((10, 5, 4)) == 14 and bench.icp_launches((10, 5, 4, 4)) == 18
