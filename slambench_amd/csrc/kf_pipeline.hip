@@ -731,6 +731,8 @@ void kfh_destroy(kfh_context *c) {
 
 void kfh_reset(kfh_context *c) {
     flush_frame(c);
+    if (c->error == KFH_ERR_BARRIER) c->error = KFH_OK;   // a new sequence on a fresh volume: the failed frame is history
+    c->clear_integrated = false;
     launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     HIP_TRY(hipMemsetAsync(c->d_skip, 0, launch::skip_grid_bytes(c->volRes[0], c->volRes[1], c->volRes[2]), c->stream));
 }
