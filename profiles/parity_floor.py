@@ -52,6 +52,9 @@ def case(name, n, W, H, res, pyramid=(10, 5, 4), ratio=1, irate=2):
 
 if __name__ == "__main__":
     n_big = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    if len(sys.argv) > 2 and sys.argv[2] == "only":
+        case("640x480 256^3", n_big, 640, 480, (256,) * 3)
+        sys.exit(0)
     case("160x120 64^3", 10, 160, 120, (64,) * 3)
     case("160x120 -c 2 48^3 (4,3)", 10, 160, 120, (48,) * 3, (4, 3), 2)
     case("160x120 32^3 (6,)", 10, 160, 120, (32,) * 3, (6,))
