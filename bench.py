@@ -310,7 +310,10 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
     while prof_every > 1 and math.gcd(prof_every, irate) != 1:     # integrate runs on frames = 0 (mod -r): the sampled frames must meet them
         prof_every += 1
     # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
-    wl = load_workload(args, rank, n_frames + V_FRAMES, W, H)
+    # (the CPU baseline wants ~15 s of work whatever --steps is: a synthetic stream is generated long enough for it; the GPU
+    # legs use its first warmup + steps frames)
+    cpu_frames = 150 if (world == 1 and not args.no_cpu_baseline and args.raw is None) else 0
+    wl = load_workload(args, rank, max(n_frames, cpu_frames) + V_FRAMES, W, H)
     d_depth = torch.from_numpy(wl.depth_mm.view(np.int16)).cuda()
 
     # The secondary leg (the same loop plus the three renders and their read-back) runs FIRST: it is a measurement of its own
@@ -365,7 +368,7 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
 
     cpu, v_distinct = (None, None)
     if not args.no_cpu_baseline and world == 1:
-        cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, n_frames + V_FRAMES)
+        cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, wl.depth_mm.shape[0])
     elif not args.no_cpu_baseline:
         # N > 1: no CPU baseline (rank 0 at N = 1 only), but raycast's algorithmic bytes still need V: the oracle runs just far
         # enough to have a surface to cast at (6 frames) and counts on the two that follow
