@@ -92,6 +92,7 @@ def lib(omp: bool = False):
         "orc_kfusion_counters": (cp, [vp]),
         "orc_kfusion_set_counting": (None, [vp, i]),
         "orc_set_omp_reduce_mode": (None, [i]),
+        "orc_set_omp_threads": (None, [i]),
         "orc_kfusion_buffer": (vp, [vp, C.c_char_p, C.POINTER(C.c_ulonglong)]),
     }
     for name_, (res, args) in sig.items():
@@ -100,6 +101,11 @@ def lib(omp: bool = False):
         fn.argtypes = args
     _libs[name] = L
     return L
+
+
+def set_omp_threads(n: int) -> None:
+    """Thread count of the -fopenmp build from now on."""
+    lib(True).orc_set_omp_threads(int(n))
 
 
 def set_omp_reduce_mode(reference_style: bool) -> None:

@@ -17,6 +17,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace orc;
 
@@ -363,6 +366,14 @@ void orc_track(void *output, const float *inVertex, const float *inNormal, unsig
 // (SURVEY N8).  Mode 1 is what tests/test_hip_fullsize.py measures the reference's own CPP-vs-OpenMP noise floor with.
 static int g_reduce_mode = 0;
 void orc_set_omp_reduce_mode(int reference_style) { g_reduce_mode = reference_style ? 1 : 0; }
+// threads of the -fopenmp build from now on (0 = leave as is); the re-associated reduction depends on the count
+void orc_set_omp_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 #ifdef _OPENMP
 static void reduce_rows_reference_omp(float *out, const TrackRec *J, unsigned JW, unsigned W, unsigned H) {
