@@ -1146,8 +1146,9 @@ __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict_
 }
 
 // =====================================================================================
-// integrateKernel (cpp:628-673).  A wave owns 64 consecutive x of one (y, z-chunk): every voxel access is
-// a full 256-byte line of the x-fastest short2 grid.  The camera-space position is carried along z by
+// integrateKernel (cpp:628-673).  A wave owns a 16 x 4 patch of (x, y) columns of one z-chunk (KFH_INT_TX; a block 32 x 8 columns):
+// every voxel access is four 64-byte segments of the x-fastest short2 grid, and the compact footprint keeps the wave's lanes
+// together in what they find (round 1 used 64 x 1: full 256-byte lines, but rows 1.2 m long that cut through everything).  The camera-space position is carried along z by
 // repeated addition exactly like the CPU loop (cpp:645-646); a thread that starts at z0 > 0 first replays
 // the z0 additions in registers so that its float state carries the bits of the serial march.
 // The six running sums are kept as three float pairs and advanced with packed adds (v_pk_add_f32).
@@ -1184,6 +1185,19 @@ __device__ __forceinline__ unsigned outside_bits(float camx, float camy, float c
     return m;
 }
 
+#ifndef KFH_INT_BX
+#define KFH_INT_BX 32
+#endif
+#ifndef KFH_INT_BY
+#define KFH_INT_BY 8
+#endif
+#ifndef KFH_INT_TX
+#define KFH_INT_TX 16
+#endif
+constexpr unsigned INT_BX = KFH_INT_BX, INT_BY = KFH_INT_BY, INT_TX = KFH_INT_TX;
+static_assert(INT_BX * INT_BY == 256 && INT_BX % INT_TX == 0 && 64 % INT_TX == 0 && (INT_BX / INT_TX) * (INT_BY / (64 / INT_TX)) == 4,
+              "a block of k_integrate is 256 columns = four waves of INT_TX x (64 / INT_TX)");
+
 template <int IB>
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
@@ -1201,7 +1215,13 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
     const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned vb = order ? order[slot] : slot;
     const unsigned vbx = vb % gridDim.x, vby = (vb / gridDim.x) % gridDim.y, vbz = vb / (gridDim.x * gridDim.y);
-    const unsigned x = vbx * 64 + threadIdx.x, y = vby * 4 + threadIdx.y;
+    // Columns of a block: INT_BX x INT_BY; of a wave: INT_TX x (64 / INT_TX), the waves side by side in x first.  A compact
+    // wave footprint keeps the 64 lanes together in what they find - inside or outside the frustum, in front of or behind
+    // the surface - and a row of INT_TX voxels is still a 64-byte segment at 16 (profiles/r02_sweeps.md).
+    const unsigned wave_ = threadIdx.y, lane_ = threadIdx.x;
+    constexpr unsigned WAVES_X = INT_BX / INT_TX, TILE_Y = 64 / INT_TX;
+    const unsigned x = vbx * INT_BX + (wave_ % WAVES_X) * INT_TX + lane_ % INT_TX;
+    const unsigned y = vby * INT_BY + (wave_ / WAVES_X) * TILE_Y + lane_ / INT_TX;
     unsigned updated = 0, work = 0;
     if (x < sx && y < sy) {
         const M4 invTrack = ip->invTrack, K = ip->K;
@@ -2359,7 +2379,7 @@ static long env_long(const char *name, long lo, long hi, long dflt) {
 // 512^3 four chunks of 128 are the measured optimum)
 static dim3 integrate_grid(unsigned sx, unsigned sy, unsigned sz, unsigned *zchunk_out) {
     static const long chunks_env = env_long("KFH_INTEGRATE_CHUNKS", 1, 64, 0);
-    const unsigned waves_xy = ((sx + 63) / 64) * sy;
+    const unsigned waves_xy = ((sx + 63) / 64) * sy;     // (waves of 64 columns, whatever their shape)
     unsigned nchunks = chunks_env ? (unsigned)chunks_env : (8192 + waves_xy - 1) / waves_xy;
     if (!chunks_env && nchunks < 4 && sz >= 256) nchunks = 4;
     if (nchunks < 1) nchunks = 1;
@@ -2367,7 +2387,7 @@ static dim3 integrate_grid(unsigned sx, unsigned sy, unsigned sz, unsigned *zchu
     if (nchunks > sz) nchunks = sz;
     const unsigned zchunk = (sz + nchunks - 1) / nchunks;
     if (zchunk_out) *zchunk_out = zchunk;
-    return dim3((sx + 63) / 64, (sy + 3) / 4, (sz + zchunk - 1) / zchunk);
+    return dim3((sx + INT_BX - 1) / INT_BX, (sy + INT_BY - 1) / INT_BY, (sz + zchunk - 1) / zchunk);
 }
 unsigned integrate_blocks(unsigned sx, unsigned sy, unsigned sz) { const dim3 g = integrate_grid(sx, sy, sz, nullptr); return g.x * g.y * g.z; }
 bool integrate_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_INTEGRATE_REORDER"); return !(e && e[0] == '0'); }(); return on; }
