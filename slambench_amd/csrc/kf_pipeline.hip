@@ -416,6 +416,13 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                 side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
                 side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
                 c->int_order_stale = false;
+            } else if (c->int_order_stale && !placed && !sp && it == 1) {
+                // phase calls (no next frame to carry along): the integrate sort rides on the second launch as the raycast sort
+                // rides on the first, instead of running alone in front of k_integrate
+                std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side;
+                side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
+                side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
+                c->int_order_stale = false;
             }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
