@@ -53,6 +53,18 @@ __host__ __device__ inline void integrate_bounds(const M4 &pose, const float k[4
     *cam_bound = (fx > fy ? fx : fy) * far;
 }
 
+// The same for an arbitrary 4x4 K (the kernel-level entry point kfh_k_integrate takes a Matrix4 like integrateKernel, cpp:628):
+// |cam.i| <= (|Ki0| + |Ki1| + |Ki2|) far + |Ki3|; cam_bound covers rows 0 and 1, far_bound both |pos.z| and |cam.z|.
+__host__ __device__ inline void integrate_bounds_matrix(const M4 &pose, const M4 &K, f3 dim, float *cam_bound, float *far_bound) {
+    const float unit[4] = {1.f, 1.f, 0.f, 0.f};
+    float cb, far;
+    integrate_bounds(pose, unit, dim, &cb, &far);
+    float row[3];
+    for (int i = 0; i < 3; ++i) row[i] = (fabsf(K.m[i][0]) + fabsf(K.m[i][1]) + fabsf(K.m[i][2])) * far + fabsf(K.m[i][3]);
+    *cam_bound = row[0] > row[1] ? row[0] : row[1];
+    *far_bound = row[2] > far ? row[2] : far;
+}
+
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran
 struct IcpState { M4 pose; int done[KFH_MAX_LEVELS]; int executed; int pad[3]; };
 
@@ -158,7 +170,7 @@ void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *c
 void check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr, int *ok, hipStream_t s);
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
-               unsigned *block_order, unsigned *block_cost, hipStream_t s);
+               unsigned *block_order, unsigned *block_cost, bool k_trivial, hipStream_t s);   // k_trivial: row 2 of p->K is (0, 0, 1, 0)
 // integrate dispatch order (most expensive blocks of the previous launch first): integrate_blocks() entries (order) and
 // twice that (cost + sort keys); init with init_ray_order, sort with integrate_order or as an ICP side block (order_mode 1)
 unsigned integrate_blocks(unsigned sx, unsigned sy, unsigned sz);

@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int n
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-struct ColumnState { v2f a, b, c; };   // (pos.x, pos.y), (pos.z, cam.x), (cam.y, cam.z)
+struct ColumnState { v2f a, b; float cy, cz; };   // (pos.x, pos.y), (pos.z, cam.x), cam.y, cam.z (cz unused when KZ)
 
 // conservative "projects outside the image on this side" bits; valid only where cam.z > 0.
 // lo = -(0.5 + margin), wlim/hlim = size - 0.5 + margin:  x/z < lo => x/z + 0.5 < 0;  x/z > wlim => x/z + 0.5 > W - 1.
@@ -1198,8 +1198,21 @@ constexpr unsigned INT_BX = KFH_INT_BX, INT_BY = KFH_INT_BY, INT_TX = KFH_INT_TX
 static_assert(INT_BX * INT_BY == 256 && INT_BX % INT_TX == 0 && 64 % INT_TX == 0 && (INT_BX / INT_TX) * (INT_BY / (64 / INT_TX)) == 4,
               "a block of k_integrate is 256 columns = four waves of INT_TX x (64 / INT_TX)");
 
-template <int IB>
-__global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
+// KZ: the third row of K is (0, 0, 1, 0) (every pinhole matrix camera_matrix() builds; the launcher checks): then
+// cam.z = 0*x + 0*y + 1*z + 0 and its step 0*dx + 0*dy + 1*dz are pos.z and its step bit for bit, the two running sums are the
+// same sequence of floats, and the march carries five sums instead of six (a packed add becomes a plain one).
+template <bool KZ> __device__ __forceinline__ void march_step(ColumnState &S, v2f da, v2f db, v2f dc) {
+    S.a += da; S.b += db;
+    S.cy += dc.x;
+    if (!KZ) S.cz += dc.y;
+}
+template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) { return KZ ? S.b.x : S.cz; }
+
+#ifndef KFH_INTEGRATE_WAVES_PER_SIMD
+#define KFH_INTEGRATE_WAVES_PER_SIMD 5      // occupancy floor handed to the register allocator (5 = at most 96 VGPRs)
+#endif
+template <int IB, bool KZ>
+__global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) void k_integrate(short2 *__restrict__ vol, unsigned sx, unsigned sy, unsigned sz,
                                                    f3 dim, const float *__restrict__ depth, unsigned W, unsigned H,
                                                    const IntegrateParams *__restrict__ ip, float mu, float maxweight,
                                                    unsigned zchunk, unsigned long long *__restrict__ updated_total,
@@ -1230,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
         const f3 pos0 = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
         const f3 cam0 = xform(K, pos0);
         ColumnState S;
-        S.a = (v2f){pos0.x, pos0.y}; S.b = (v2f){pos0.z, cam0.x}; S.c = (v2f){cam0.y, cam0.z};
+        S.a = (v2f){pos0.x, pos0.y}; S.b = (v2f){pos0.z, cam0.x}; S.cy = cam0.y; S.cz = cam0.z;
         const v2f da = (v2f){delta.x, delta.y}, db = (v2f){delta.z, cameraDelta.x}, dc = (v2f){cameraDelta.y, cameraDelta.z};
         const unsigned z0 = vbz * zchunk;
         const unsigned z1 = z0 + zchunk < sz ? z0 + zchunk : sz;
@@ -1264,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             chunk_out = chunk_out || behind;
         }
         if (!chunk_out)
-        for (unsigned z = 0; z < z0; ++z) { S.a += da; S.b += db; S.c += dc; }
+        for (unsigned z = 0; z < z0; ++z) { march_step<KZ>(S, da, db, dc); }
         const size_t plane = (size_t)sx * sy;
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -1285,24 +1298,24 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             // advance over the batch; `last` is the state of its final voxel, S the state of the next batch's first
             if (nb == (unsigned)IB) {   // whole batch (all but possibly the last of a chunk): straight-line packed adds
 #pragma unroll
-                for (int i = 0; i < IB - 1; ++i) { S.a += da; S.b += db; S.c += dc; }
+                for (int i = 0; i < IB - 1; ++i) { march_step<KZ>(S, da, db, dc); }
                 last = S;
-                S.a += da; S.b += db; S.c += dc;
+                march_step<KZ>(S, da, db, dc);
             } else {
                 last = S;
                 for (unsigned i = 0; i < nb; ++i) {
                     last = S;
-                    S.a += da; S.b += db; S.c += dc;
+                    march_step<KZ>(S, da, db, dc);
                 }
             }
             {
                 const float z_f = first.b.x, z_l = last.b.x;          // pos.z
-                const float cz_f = first.c.y, cz_l = last.c.y;        // cam.z
+                const float cz_f = cam_z<KZ>(first), cz_l = cam_z<KZ>(last);
                 const bool behind = z_f < 0.00005f && z_l < 0.00005f;
                 bool outside = false;
                 if (batch_ok && cz_f > 0.05f && cz_l > 0.05f)
-                    outside = (outside_bits(first.b.y, first.c.x, cz_f, -0.75f, wlim_b, hlim_b) &
-                               outside_bits(last.b.y, last.c.x, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
+                    outside = (outside_bits(first.b.y, first.cy, cz_f, -0.75f, wlim_b, hlim_b) &
+                               outside_bits(last.b.y, last.cy, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
                 if (behind || outside || (dbg & 1)) continue;   // dbg: timing probes only (KFH_INTEGRATE_DBG)
             }
             // detailed pass over the batch, replaying the additions from its first voxel
@@ -1312,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 if ((unsigned)i < nb) {
-                    const float posz = T.b.x, cx = T.b.y, cy = T.c.x, cz = T.c.y;
+                    const float posz = T.b.x, cx = T.b.y, cy = T.cy, cz = cam_z<KZ>(T);
                     if (!(posz < 0.0001f)) {                                       // cpp:647
                         const bool far_out = cz > 0.f && outside_bits(cx, cy, cz, -0.6f, wlim, hlim) != 0u;
                         if (!far_out) {
@@ -1334,7 +1347,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
                             }
                         }
                     }
-                    T.a += da; T.b += db; T.c += dc;
+                    march_step<KZ>(T, da, db, dc);
                 }
             }
             ++work;
@@ -1346,12 +1359,13 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
             unsigned need = 0;
             float t_[IB];
-            v2f camc = first.c;               // (cam.y, cam.z), replayed like the positions below
+            float camz_i = cam_z<KZ>(first);  // cam.z of voxel i, replayed like the positions below
+            const float dz_step = KZ ? db.x : dc.y;
 #pragma unroll
-            for (int i = 0; i < IB; ++i, camc += dc) {
+            for (int i = 0; i < IB; ++i, camz_i += dz_step) {
                 if (!(live & (1u << i))) continue;
                 if (d[i] == 0) continue;                                           // cpp:655
-                const float t = d[i] - camc.y;
+                const float t = d[i] - camz_i;
                 if (t <= -mu) continue;
                 t_[i] = t;
                 need |= 1u << i;
@@ -1366,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, uns
             // of being kept in 24 registers across the two memory round trips above
             ColumnState R = first;
 #pragma unroll
-            for (int i = 0; i < IB; ++i, R.a += da, R.b += db, R.c += dc) {
+            for (int i = 0; i < IB; ++i, R.a += da, R.b += db) {
                 if (!(need & (1u << i))) continue;
                 float sdf;
                 if (t_[i] >= mu) {
@@ -2397,7 +2411,7 @@ void integrate_order(unsigned *block_order, unsigned *block_cost, unsigned n, hi
 
 void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, const float *depth, unsigned W, unsigned H,
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
-               unsigned *block_order, unsigned *block_cost, hipStream_t s) {
+               unsigned *block_order, unsigned *block_cost, bool k_trivial, hipStream_t s) {
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
     // timing probes (results are wrong with them): 1 every batch rejected, 2 stop after the projection pass, 4 stop after the depth
     // classification, 8 no whole-chunk reject; KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
@@ -2413,10 +2427,17 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     const bool reorder = integrate_reorder_enabled() && block_order && block_cost;
     const unsigned *order = reorder ? block_order : nullptr;
     unsigned *cost = reorder ? block_cost : nullptr;
-    if (batch_env >= 16) k_integrate<16><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
-    else if (batch_env >= 8) k_integrate<8><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
-    else if (batch_env >= 4) k_integrate<4><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
-    else k_integrate<1><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);
+    // (k_trivial: the third row of K is (0, 0, 1, 0), see KZ)
+#define KFH_LAUNCH_INTEGRATE(IB_)                                                                                        \
+    do {                                                                                                                 \
+        if (k_trivial) k_integrate<IB_, true><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);  \
+        else k_integrate<IB_, false><<<grid, block_rows(), 0, s>>>(v, sx, sy, sz, dim, depth, W, H, p, mu, maxweight, zchunk, updated_total, skip_flags, dbg, trace, order, cost);           \
+    } while (0)
+    if (batch_env >= 16) KFH_LAUNCH_INTEGRATE(16);
+    else if (batch_env >= 8) KFH_LAUNCH_INTEGRATE(8);
+    else if (batch_env >= 4) KFH_LAUNCH_INTEGRATE(4);
+    else KFH_LAUNCH_INTEGRATE(1);
+#undef KFH_LAUNCH_INTEGRATE
     launched("k_integrate");
     wt.dump();
 }

@@ -453,7 +453,7 @@ static void enqueue_integrate(kfh_context *c, float mu) {
     prof_begin(c, KFH_PROF_INTEGRATE);
     launch::integrate(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim, c->d_floatDepth, c->W, c->H,
                       &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->use_skip ? c->d_skip : nullptr,
-                      c->d_int_order, c->d_int_cost, c->stream);
+                      c->d_int_order, c->d_int_cost, true /* K = camera_matrix(k) */, c->stream);
     // (a launch the device-side gate disables leaves all costs at zero: the sort then keeps the identity order)
     c->int_order_stale = launch::integrate_reorder_enabled();
     prof_end(c, KFH_PROF_INTEGRATE);
@@ -1251,12 +1251,10 @@ void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], c
     IntegrateParams hp;
     std::memset(&hp, 0, sizeof hp);
     hp.invTrack = load16(inv_track16); hp.K = load16(K16); hp.enabled = 1;
-    {
-        const float k4[4] = {hp.K.m[0][0], hp.K.m[1][1], hp.K.m[0][2], hp.K.m[1][2]};
-        integrate_bounds(inverse(hp.invTrack), k4, mk3(dim[0], dim[1], dim[2]), &hp.cam_bound, &hp.far_bound);
-    }
+    integrate_bounds_matrix(inverse(hp.invTrack), hp.K, mk3(dim[0], dim[1], dim[2]), &hp.cam_bound, &hp.far_bound);
     HIP_TRY(hipMemcpy(d, &hp, sizeof hp, hipMemcpyHostToDevice));
-    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, nullptr, nullptr, s);
+    const bool k_trivial = hp.K.m[2][0] == 0.f && hp.K.m[2][1] == 0.f && hp.K.m[2][2] == 1.f && hp.K.m[2][3] == 0.f;
+    launch::integrate(vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), depth, w, h, d, mu, maxw, nullptr, nullptr, nullptr, nullptr, k_trivial, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 

@@ -61,7 +61,8 @@ def run(hip, orc, seed=7, trials=12, verbose=False):
 def run_extreme(hip, orc, seed=3, trials=12, verbose=False):
     """integrateKernel where its shortcuts are at their limits: arbitrary rotations (the volume seen upside down, edge-on, from a
     corner), cameras inside, on the faces of and outside the volume, intrinsics scaled up to 16x (the rounding bound of the
-    whole-chunk / batch rejects fails and every voxel must take the reference tests), depth images that are planes, noise or
+    whole-chunk / batch rejects fails and every voxel must take the reference tests), every fifth trial a K whose third row is
+    not (0, 0, 1, 0), depth images that are planes, noise or
     mostly holes - two integrations each, bit for bit against the oracle."""
     rng = np.random.default_rng(seed)
     dev = Dev()
@@ -72,7 +73,9 @@ def run_extreme(hip, orc, seed=3, trials=12, verbose=False):
         dim = tuple(float(v) for v in rng.uniform(1.0, 6.0, 3))
         scale = float(rng.choice([1.0, 1.0, 4.0, 16.0]))
         k = [481.2 * W / 640 * scale, 480.0 * H / 480 * scale, W / 2.0 + rng.uniform(-20, 20), H / 2.0 + rng.uniform(-20, 20)]
-        K = orc.camera_matrix(k)
+        K = orc.camera_matrix(k).copy()
+        if trial % 5 == 4:                                         # a projective third row: cam.z is no longer pos.z
+            K[2] = [0.03 * ((trial % 3) - 1), -0.02, 1.0 + 0.01 * (trial % 7), 0.02 * ((trial % 4) - 1.5)]
         vol = orc.init_volume(res, omp=True)
         d_vol = dev.put(vol.copy())
         for f in range(2):

@@ -266,6 +266,29 @@ def test_integrate(hip, dev, orc, scene, res):
     assert total > 0.02 * np.prod(res)                  # the case exercises real updates
 
 
+@pytest.mark.parametrize("row2", [(0.0, 0.0, 1.0, 0.0), (0.01, -0.02, 0.97, 0.05), (0.0, 0.0, 1.0, 1e-3), (0.0, 0.0, 2.0, 0.0)])
+def test_integrate_general_projection_matrix(hip, dev, orc, scene, row2):
+    """integrateKernel takes K as a Matrix4 (cpp:628): nothing says its third row is (0, 0, 1, 0).  The kernel carries cam.z
+    as a running sum of its own unless that row is exactly the pinhole one (then cam.z IS pos.z, bit for bit); both forms and
+    a skewed first row against the CPU loop."""
+    s = scene["stream"]
+    K = orc.camera_matrix(s.k).copy()
+    K[2] = row2
+    K[0, 1] = 0.0 if row2 == (0.0, 0.0, 1.0, 0.0) else 2.5
+    res = (64, 48, 72)
+    vol_ref = orc.init_volume(res)
+    d_vol = dev.put(vol_ref.copy())
+    total = 0
+    for f in range(3):
+        depth = orc.mm2meters(s.depth_mm[f], s.width, s.height)
+        inv_track = orc.inverse(s.poses[f].astype(np.float32))
+        total += orc.integrate(vol_ref, util.VOL_DIM, depth, inv_track, K)
+        hip.kfh_k_integrate(d_vol.data_ptr(), u32(res), f32(util.VOL_DIM), dev.put(depth).data_ptr(), s.width, s.height,
+                            m16(inv_track), m16(K), 0.1, 100.0, dev.stream)
+        assert np.array_equal(dev.get(d_vol), vol_ref), "TSDF differs after frame %d" % f
+    assert total > 0.01 * np.prod(res)
+
+
 def test_integrate_no_depth_is_identity(hip, dev, orc):
     res = (32, 32, 32)
     vol = orc.init_volume(res)
