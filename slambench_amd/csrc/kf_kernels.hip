@@ -460,18 +460,57 @@ __device__ __forceinline__ void halve(const float (&in)[2 * N], float (&out)[N],
         out[i] = keep + __shfl_xor(give, partner, 64);
     }
 }
+// The same step for the partners lane ^ 32 and lane ^ 16 without the two selects and the LDS crossbar: gfx950's
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another (v_permlane16_swap: the odd rows
+// of 16 lanes with the even rows), after which "what I keep" and "what my partner gave" sit in the two registers of every
+// lane.  Same pairs, same sums, same bits as halve().  (Inline assembly: this compiler's __builtin_amdgcn_permlane32_swap
+// hands back its first result twice; the s_nops stand for the wait states the compiler puts around the instruction when it
+// schedules it itself - a VALU result feeding a swap, a swap feeding a swap - which it cannot see inside an asm block.)
+#ifndef KFH_REDUCE_SWAP
+#define KFH_REDUCE_SWAP 1
+#endif
+template <int N, int PARTNER>
+__device__ __forceinline__ void halve_swap(const float (&in)[2 * N], float (&out)[N]) {
+    static_assert(PARTNER == 32 || PARTNER == 16, "row swaps");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float a = in[i], b = in[i + N];
+        if (PARTNER == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        out[i] = a + b;
+    }
+}
+// ... and for lane ^ 8, ^ 2, ^ 1, which stay inside a row of 16 lanes: a DPP operand of the addition (row rotate by 8, quad permutes)
+template <int N, int CTRL>
+__device__ __forceinline__ void halve_dpp(const float (&in)[2 * N], float (&out)[N], bool hi) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float keep = hi ? in[i + N] : in[i];
+        const float give = hi ? in[i] : in[i + N];
+        out[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), CTRL, 0xF, 0xF, true));
+    }
+}
 
 template <int NT>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__restrict__ partial) {
     __shared__ float sm[NT / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a16[16], a8[8], a4[4], a2[2], a1[1];
+#if KFH_REDUCE_SWAP
+    halve_swap<16, 32>(acc, a16);
+    halve_swap<8, 16>(a16, a8);
+    halve_dpp<4, 0x128>(a8, a4, lane & 8);          // row_ror:8
+    halve<2>(a4, a2, lane & 4, 4);
+    halve_dpp<1, 0x4E>(a2, a1, lane & 2);           // quad_perm [2, 3, 0, 1]
+    const float v = a1[0] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1[0]), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+#else
     halve<16>(acc, a16, lane & 32, 32);
     halve<8>(a16, a8, lane & 16, 16);
     halve<4>(a8, a4, lane & 8, 8);
     halve<2>(a4, a2, lane & 4, 4);
     halve<1>(a2, a1, lane & 2, 2);
     const float v = a1[0] + __shfl_xor(a1[0], 1, 64);
+#endif
     const int index = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     if ((lane & 1) == 0) sm[wave][index] = v;
     __syncthreads();
