@@ -1247,6 +1247,9 @@ template <bool KZ> __device__ __forceinline__ void march_step(ColumnState &S, v2
 }
 template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) { return KZ ? S.b.x : S.cz; }
 
+#ifndef KFH_INT_IDLE_EXIT
+#define KFH_INT_IDLE_EXIT 1
+#endif
 #ifndef KFH_INTEGRATE_WAVES_PER_SIMD
 #define KFH_INTEGRATE_WAVES_PER_SIMD 5      // occupancy floor handed to the register allocator (5 = at most 96 VGPRs)
 #endif
@@ -1258,14 +1261,21 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                                                    unsigned char *__restrict__ skip_flags, int dbg,
                                                    unsigned long long *__restrict__ trace,
                                                    const unsigned *__restrict__ order, unsigned *__restrict__ cost) {
-    if (!ip->enabled) return;
+    // everything a wave needs before it can decide anything - the launch parameters the control operation left in DevState
+    // (gate, matrices, bounds) and its entry of the dispatch order - is requested in one go: written in the order of use
+    // these are five dependent scalar round trips, ~1.5 us at the head of every wave, two thirds of which leave right after
+    const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const IntegrateParams P = *ip;
+    const unsigned vb = order ? order[slot] : slot;
+    // (the empty statement "uses" one word of every piece the structure is fetched in, so that the compiler cannot put the
+    // matrices' loads back behind the gate)
+    asm volatile("" : : "s"(P.invTrack.m[0][0]), "s"(P.invTrack.m[2][0]), "s"(P.K.m[0][0]), "s"(P.K.m[2][0]), "s"(vb));
+    if (!P.enabled) return;
     const unsigned long long t_start = trace ? wall_clock64() : 0ull;
     // Launch slot -> block of the (x / 64, y / 4, z-chunk) grid.  As in k_raycast: the launch ends with its slowest
     // wave (a column chunk lying in the truncation band costs ~10x one outside the frustum), so the blocks that were
     // expensive in the previous launch are dispatched first instead of wherever x-y-z order puts them (at 512^3 the
     // far chunks, i.e. the band, used to start 55 us into a 170 us launch).
-    const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned vb = order ? order[slot] : slot;
     const unsigned vbx = vb % gridDim.x, vby = (vb / gridDim.x) % gridDim.y, vbz = vb / (gridDim.x * gridDim.y);
     // Columns of a block: INT_BX x INT_BY; of a wave: INT_TX x (64 / INT_TX), the waves side by side in x first.  A compact
     // wave footprint keeps the 64 lanes together in what they find - inside or outside the frustum, in front of or behind
@@ -1276,7 +1286,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
     const unsigned y = vby * INT_BY + (wave_ / WAVES_X) * TILE_Y + lane_ / INT_TX;
     unsigned updated = 0, work = 0;
     if (x < sx && y < sy) {
-        const M4 invTrack = ip->invTrack, K = ip->K;
+        const M4 invTrack = P.invTrack, K = P.K;
         const f3 delta = rotate(invTrack, mk3(0.f, 0.f, dim.z / sz));
         const f3 cameraDelta = rotate(K, delta);
         const f3 pos0 = xform(invTrack, mk3((x + 0.5f) * dim.x / sx, (y + 0.5f) * dim.y / sy, (0 + 0.5f) * dim.z / sz));
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         if (!(dbg & 8)) {
             const float zf = (float)z0, zl = (float)(z1 - 1);
             const float n_err = (float)(sz + 4) * 5.9604645e-8f;
-            const float E = n_err * ip->cam_bound, Ez = n_err * ip->far_bound;
+            const float E = n_err * P.cam_bound, Ez = n_err * P.far_bound;
             const float pzf = __builtin_fmaf(zf, delta.z, pos0.z), pzl = __builtin_fmaf(zl, delta.z, pos0.z);
             const float cxf = __builtin_fmaf(zf, cameraDelta.x, cam0.x), cxl = __builtin_fmaf(zl, cameraDelta.x, cam0.x);
             const float cyf = __builtin_fmaf(zf, cameraDelta.y, cam0.y), cyl = __builtin_fmaf(zl, cameraDelta.y, cam0.y);
@@ -1326,7 +1336,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         // 0.2 of the 0.25 px margin.  max|cam.x| over the volume is bounded per launch (IntegrateParams::cam_bound, from the
         // intrinsics and the camera position): where the bound fails - huge intrinsics or volumes - no batch is rejected
         // on its end voxels and every voxel takes the reference tests.
-        const bool batch_ok = (float)IB * 5.9604645e-8f * ip->cam_bound < 0.2f * 0.05f;
+        const bool batch_ok = (float)IB * 5.9604645e-8f * P.cam_bound < 0.2f * 0.05f;
         const float wlim = (float)W - 0.4f, hlim = (float)H - 0.4f;
         const float wlim_b = (float)W - 0.25f, hlim_b = (float)H - 0.25f;
         const float ptol = 2e-6f * (float)(W > H ? W : H);
@@ -1441,6 +1451,11 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
         }
     }
+#if KFH_INT_IDLE_EXIT
+    // two of three waves examined nothing (their chunks lie outside the frustum): nothing to add to the cost table or the
+    // counter, so they leave here instead of running two six-step wave reductions over zeros
+    if (!trace && __builtin_amdgcn_ballot_w64((work | updated) != 0u) == 0ull) return;
+#endif
     if (cost || trace) {   // cost of the block = the busiest lane of its waves: batches examined + 4 x batches updated
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) work = umax_(work, (unsigned)__shfl_xor((int)work, off, 64));
@@ -1916,7 +1931,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
                                                  unsigned H, const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                  unsigned sz, f3 dim, const RayParams *__restrict__ rp, float nearPlane,
                                                  float farPlane, float step, float largestep, SkipGrid sg, f3 rdim) {
-    if (!rp->enabled) return;
+    const RayParams R = *rp;      // gate and view matrix in one request, the dispatch-order entry with them (see k_integrate)
     const unsigned long long t_start = sg.trace ? wall_clock64() : 0ull;
     // Launch slot -> screen tile.  Workgroups are dispatched in slot order and the launch ends with its slowest wave, so
     // the tiles whose rays marched longest in the previous frame (grazing views along a surface: up to 4x the mean) go
@@ -1924,15 +1939,18 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
     // profiles/r01_sweeps.md).  The order also keeps the tiles of a 64x64-pixel super-tile on one XCD (ray_order_block).
     // It only decides WHEN and WHERE a tile is computed, never what.
     const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x;
-    if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
-        track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
     // A dispatch tile is 2x2 wave tiles.  With workgroups smaller than that (KFH_RAY_BLOCK_WAVES < 4, which pack the CUs
     // better) a tile is PARTS workgroups whose slots are 8 apart, i.e. on the same XCD: slot = 8 * PARTS * j + 8 * part + class.
     constexpr unsigned PARTS = 4 / KFH_RAY_BLOCK_WAVES;
     const unsigned tslot = PARTS == 1 ? slot : (slot / (8 * PARTS)) * 8 + (slot % 8);
     const unsigned part = PARTS == 1 ? 0u : (slot / 8) % PARTS;
-    if (tslot >= sg.tiles_x * sg.tiles_y) return;      // (padding of the launch to a multiple of 8 * PARTS slots)
-    const unsigned tile = sg.order ? sg.order[tslot] : tslot;
+    const bool padding = tslot >= sg.tiles_x * sg.tiles_y;      // (the launch is padded to a multiple of 8 * PARTS slots)
+    const unsigned tile = (sg.order && !padding) ? sg.order[tslot] : tslot;
+    asm volatile("" : : "s"(R.view.m[0][0]), "s"(R.view.m[2][0]), "s"(tile));
+    if (!R.enabled) return;
+    if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
+        track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
+    if (padding) return;
     unsigned x, y;
     {
         const unsigned tx = tile % sg.tiles_x, ty = tile / sg.tiles_x;
@@ -1941,7 +1959,7 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
         tile_pixel<Q>(x, y, tx * (2 / RAY_WX) + px_, ty * (2 / RAY_WY) + py_);
     }
     if (x >= W || y >= H) return;     // uniform per ray group: all Q lanes share the pixel
-    const M4 view = rp->view;
+    const M4 view = R.view;
     VolViewT<FD> v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.rdim = rdim; v.plane = (size_t)sx * sy;
     int work = 0;
