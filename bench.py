@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline / roofline_other   icp loop, k_integrate, k_raycast: algorithmic bytes / HIP-event time measured in this run
   cpu_baseline                the OpenMP oracle timed on the host cores on a bounded prefix of the same stream
   fps_total                   the same queued loop plus the three renders and their read-back
+  fps_queued_host_input       the same queued loop with every frame handed over as pageable host memory (H2D inside the loop)
   fps_host_buffers            what a reference-style caller gets (benchmark.cpp:125-158): kfusion-benchmark-hip itself on a
                               `.raw` of the same frames - pageable host depth, four phase calls, a device sync at every tock()
   ate_m                       ATE of the estimated trajectory, scored as checkPos.py scores a log
@@ -74,7 +75,8 @@ def parse():
     ap.add_argument("--traj", type=int, default=None, help="ICL-NUIM trajectory 0-3: picks the Makefile's -s/-p/-k line (default: from the file name, else 2)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-total", action="store_true", help="skip the secondary loop with renders")
+    ap.add_argument("--no-total", action="store_true", help="skip the secondary loops (renders; frames handed over as host memory)")
+    ap.add_argument("--host-input", action="store_true", help="profiling aid: the timed loop itself takes its frames from pageable host memory (the line then says so)")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the kfusion-benchmark-hip leg (fps_host_buffers)")
     ap.add_argument("--profile-every", type=int, default=None,
                     help="an HIP-event pair around ONE of icp/integrate/raycast (rotating) on every n-th timed frame; default "
@@ -122,9 +124,9 @@ def load_workload(args, rank, n_frames, W, H):
 class Leg:
     """One context (plus optional extra ones) stepping through the stream with kfh_compute_frame."""
 
-    def __init__(self, kfusion, wl, d_depth, cfg, device, with_renders, extra_streams=0):
+    def __init__(self, kfusion, wl, d_depth, cfg, device, with_renders, extra_streams=0, host_input=False):
         W, H, vres, pyramid, irate, zrate = cfg
-        self.cfg, self.wl, self.with_renders = cfg, wl, with_renders
+        self.cfg, self.wl, self.with_renders, self.host_input = cfg, wl, with_renders, host_input
         mk = lambda: kfusion.Kfusion((W, H), (vres,) * 3, (wl.volume_size,) * 3, wl.init_pos, pyramid, device=device)
         self.kf = mk()
         self.others = [mk() for _ in range(extra_streams)]
@@ -136,7 +138,9 @@ class Leg:
         W, H, _, _, irate, zrate = self.cfg
         k = list(self.wl.k)
         for ctx in [self.kf] + self.others:
-            ctx.compute_frame(self.base + f * self.frame_bytes, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
+            # host_input: the frame is handed over as pageable host memory, like Kfusion::computeFrame's inputDepth (PCIe inside the loop)
+            src = self.wl.depth_mm[f] if self.host_input else self.base + f * self.frame_bytes
+            ctx.compute_frame(src, (W, H), k, irate, TRACKING_RATE, ICP_THRESHOLD, MU, f)
         if self.with_renders:   # benchmark.cpp:153-156
             L, h = self.kf.L, self.kf.h
             u8 = C.POINTER(C.c_uint8)
@@ -327,8 +331,17 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
         j2 = multi.aggregate(multi.RankStats(args.steps, e2, failed=0 if err2 is None else 1), dist, device=coll_device)
         fps_total = None if j2.failed else j2.fps
 
+    # ... and the queued loop fed from pageable host memory (PCIe-inclusive; never the headline value)
+    fps_host_input = None
+    if not args.no_total:
+        e3, leg3, err3 = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, host_input=True), torch, dist, multi, args.warmup, args.steps, 0, coll_device)
+        if leg3 is not None:
+            leg3.close()
+        j3 = multi.aggregate(multi.RankStats(args.steps, e3, failed=0 if err3 is None else 1), dist, device=coll_device)
+        fps_host_input = None if j3.failed else j3.fps
+
     spg = max(1, args.streams_per_gpu)
-    elapsed, leg, err = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, spg - 1), torch, dist, multi,
+    elapsed, leg, err = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, spg - 1, host_input=args.host_input), torch, dist, multi,
                                   args.warmup, args.steps, prof_every, coll_device)
     failed, errs = 0, [0.0]
     prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = None
@@ -440,8 +453,8 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
                        "executed_iterations_per_frame_by_level": [round(v / max(1, n_frames), 2) for v in icp_by_level]}
     dominant = max(roof, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if roof else None
     out = {
-        "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), device-resident input, queued frames, "
-                  "living-room stream %dx%d -c 1 @%d^3" % (W, H, vres),
+        "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), %s, queued frames, "
+                  "living-room stream %%dx%%d -c 1 @%%d^3" % ("PAGEABLE HOST INPUT (--host-input)" if args.host_input else "device-resident input") % (W, H, vres),
         "value": round(total_frames / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t_max / (args.steps * spg) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": wl.data,
@@ -450,6 +463,7 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
                                   ",".join("%g" % v for v in wl.init_factors), ",".join("%g" % v for v in wl.k)),
                    "frames_per_gpu": args.steps * spg, "streams_per_gpu": spg, "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks},
         "fps_total": None if fps_total is None else round(fps_total, 2),
+        "fps_queued_host_input": None if fps_host_input is None else round(fps_host_input, 2),
         "fps_host_buffers": host,
         "ate_m": ate,
         "phase_us": {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items() if v[1]},

@@ -100,6 +100,13 @@ struct kfh_context {
     uint16_t *h_input[2] = {nullptr, nullptr};
     hipEvent_t input_done[2] = {nullptr, nullptr};
     int input_slot = 0;
+    // queued frames handed over as host memory (stage_input_queued): an upload stream, a ring of pinned and of device buffers
+    static constexpr int Q_SLOTS = 8, Q_ROUND = 4;
+    hipStream_t copy_stream = nullptr;
+    uint16_t *q_host[Q_SLOTS] = {}, *q_dev[Q_SLOTS] = {};
+    hipEvent_t q_copied[Q_SLOTS] = {}, q_round[Q_SLOTS / Q_ROUND] = {};
+    size_t q_capacity = 0;
+    int q_slot = 0, q_last = -1;
     DevState *h_state = nullptr;
     uchar4 *h_render[3] = {nullptr, nullptr, nullptr};
     std::vector<PendingCopy> pending;
@@ -552,6 +559,48 @@ static const uint16_t *stage_input(kfh_context *c, const uint16_t *host, unsigne
     return c->d_input;
 }
 
+// The same for a QUEUED frame (kfh_compute_frame with a host pointer).  Nothing waits for a queued frame, and an upload in
+// the compute stream is ~20 us between two kernels during which the chip does nothing.  So the upload goes through a stream of
+// its own, from a ring of pinned buffers into a ring of device buffers, while the kernels of the frames queued before it are
+// still running; the compute stream waits for the event behind the copy (one barrier packet per frame).  Nothing on the
+// device orders the copy against the readers of the buffer it overwrites - a cross-stream wait in front of an SDMA copy makes
+// hipMemcpyAsync block on the host, measured - the HOST does: a ring slot is reused eight frames later, and one event per
+// four frames, recorded in the compute stream behind the readers, is synchronised before a round of slots is written again.
+// The caller may reuse its own buffer when kfh_compute_frame returns, as with Kfusion::computeFrame.
+// (Reading the pinned frame in place from the bilateral side blocks was tried: 4100 frames/s against 4860 - a stencil over PCIe.)
+static const uint16_t *stage_input_queued(kfh_context *c, const uint16_t *host, unsigned inW, unsigned inH) {
+    static const bool in_stream = [] { const char *e = getenv("KFH_UPLOAD_STREAM"); return e && e[0] == '0'; }();
+    if (in_stream) return stage_input(c, host, inW, inH);
+    const size_t bytes = (size_t)inW * inH * sizeof(uint16_t);
+    constexpr int SLOTS = kfh_context::Q_SLOTS, ROUND = kfh_context::Q_ROUND;
+    if (!c->copy_stream) {
+        if (!HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking))) return nullptr;
+        for (int i = 0; i < SLOTS; ++i) if (!HIP_TRY(hipEventCreateWithFlags(&c->q_copied[i], hipEventDisableTiming))) return nullptr;
+        for (int r = 0; r < SLOTS / ROUND; ++r) if (!HIP_TRY(hipEventCreateWithFlags(&c->q_round[r], hipEventDisableTiming))) return nullptr;
+    }
+    if (bytes > c->q_capacity) {
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < SLOTS; ++i) {
+            if (c->q_host[i]) { HIP_TRY(hipHostFree(c->q_host[i])); c->q_host[i] = nullptr; }
+            if (c->q_dev[i]) { HIP_TRY(hipFree(c->q_dev[i])); c->q_dev[i] = nullptr; }
+            if (!HIP_TRY(hipHostMalloc(&c->q_host[i], bytes, hipHostMallocDefault)) || !HIP_TRY(hipMalloc(&c->q_dev[i], bytes))) return nullptr;
+        }
+        c->q_capacity = bytes;
+        c->q_slot = 0;
+    }
+    const int slot = c->q_slot;
+    c->q_slot = (c->q_slot + 1) % SLOTS;
+    // (an event never recorded yet is complete; the event of a round covers the copies of its slots too: their readers ran after them)
+    if (slot % ROUND == 0 && !HIP_TRY(hipEventSynchronize(c->q_round[slot / ROUND]))) return nullptr;
+    std::memcpy(c->q_host[slot], host, bytes);
+    bool ok = HIP_TRY(hipMemcpyAsync(c->q_dev[slot], c->q_host[slot], bytes, hipMemcpyHostToDevice, c->copy_stream));
+    ok = ok && HIP_TRY(hipEventRecord(c->q_copied[slot], c->copy_stream));
+    ok = ok && HIP_TRY(hipStreamWaitEvent(c->stream, c->q_copied[slot], 0));
+    c->q_last = slot;       // kfh_compute_frame records the round's event once the readers of its last buffer are queued
+    return ok ? c->q_dev[slot] : nullptr;
+}
+
 static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_t res[3], const float dims[3],
                                   const M4 &pose, const float initPose3[3], const int32_t *pyramid, int32_t n_levels,
                                   int32_t device, void *stream) {
@@ -731,6 +780,14 @@ void kfh_destroy(kfh_context *c) {
     hipFree(c->d_state); hipFree(c->d_log);
     for (int i = 0; i < 3; ++i) { hipFree(c->d_render[i]); if (c->h_render[i]) hipHostFree(c->h_render[i]); }
     for (int i = 0; i < 2; ++i) { if (c->h_input[i]) hipHostFree(c->h_input[i]); if (c->input_done[i]) hipEventDestroy(c->input_done[i]); }
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    for (int i = 0; i < kfh_context::Q_SLOTS; ++i) {
+        if (c->q_host[i]) hipHostFree(c->q_host[i]);
+        if (c->q_dev[i]) hipFree(c->q_dev[i]);
+        if (c->q_copied[i]) hipEventDestroy(c->q_copied[i]);
+    }
+    for (int r = 0; r < kfh_context::Q_SLOTS / kfh_context::Q_ROUND; ++r) if (c->q_round[r]) hipEventDestroy(c->q_round[r]);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->h_state) hipHostFree(c->h_state);
     for (int p = 0; p < KFH_PROF_COUNT; ++p) for (hipEvent_t e : c->prof_events[p]) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -853,13 +910,16 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
             return KFH_ERR_INVALID_RATIO;
         }
         NextFrameWork nw;
-        nw.d_in = depth_is_device ? depth_mm : stage_input(c, depth_mm, in_width, in_height);
+        c->q_last = -1;
+        nw.d_in = depth_is_device ? depth_mm : stage_input_queued(c, depth_mm, in_width, in_height);
         if (!nw.d_in) return KFH_ERR_HIP;
         nw.inW = in_width; nw.inH = in_height;
         nw.pyramid = (frame % tracking_rate) == 0;
         nw.frame = frame; nw.tracking_rate = tracking_rate;
         for (int i = 0; i < 4; ++i) nw.k[i] = k[i];
         finish_pending_frame(c, &nw);    // the previous queued frame's second part, with this frame's first part riding on it
+        if (c->q_last >= 0 && c->q_last % kfh_context::Q_ROUND == kfh_context::Q_ROUND - 1)      // the readers of this round of pinned buffers are queued
+            HIP_TRY(hipEventRecord(c->q_round[c->q_last / kfh_context::Q_ROUND], c->stream));
         c->pend.valid = true;
         c->pend.pyramid_ready = nw.pyramid;
     }

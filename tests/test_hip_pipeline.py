@@ -184,6 +184,34 @@ def test_compute_frame_equals_phases(hip, kfmod):
     a.close(); b.close()
 
 
+def test_queued_frames_from_host_memory_equal_device_resident_input(hip, kfmod):
+    """kfh_compute_frame with a host pointer uploads the frame through a stream and two device buffers of its own, overlapped
+    with the kernels queued before it; the caller may reuse its buffer as soon as the call returns (Kfusion::computeFrame's
+    inputDepth, benchmark.cpp:103-104 reads every frame into the same malloc).  Same bits as frames already resident in HBM."""
+    import torch
+    n = 12
+    s = util.small_stream(n)
+    k = list(s.k)
+    res = (64, 64, 64)
+    a, b = _make(kfmod, s, res), _make(kfmod, s, res)
+    d_all = torch.from_numpy(np.ascontiguousarray(s.depth_mm).view(np.int16)).cuda()
+    frame_bytes = s.width * s.height * 2
+    scratch = np.zeros_like(s.depth_mm[0])
+    for f in range(n):
+        a.compute_frame(d_all.data_ptr() + f * frame_bytes, (s.width, s.height), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        scratch[...] = s.depth_mm[f]
+        b.compute_frame(scratch, (s.width, s.height), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        scratch[...] = 0xFFFF                              # the caller's buffer is its own again
+    a.synchronise(); b.synchronise()
+    assert same_bits(a.get_pose(), b.get_pose())
+    assert np.array_equal(a.buffer("volume"), b.buffer("volume"))
+    assert same_bits(a.buffer("vertex"), b.buffer("vertex")) and same_bits(a.buffer("normal"), b.buffer("normal"))
+    pa, ta, ia = a.frame_log(n)
+    pb, tb, ib = b.frame_log(n)
+    assert same_bits(pa, pb) and list(ta) == list(tb) and list(ia) == list(ib) and ta[4:].all()
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("tracking_rate,integration_rate,pyramid,peek", [(1, 2, (10, 5, 4), False), (2, 3, (10, 5, 4), False),
                                                                        (1, 1, (4, 3), True), (1, 2, (6,), False), (3, 1, (5, 5, 4, 3), False)])
 def test_queued_frames_ride_on_icp_launches(hip, kfmod, tracking_rate, integration_rate, pyramid, peek):
