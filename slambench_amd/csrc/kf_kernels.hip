@@ -634,25 +634,17 @@ __global__ void k_update_pose(M4 *pose, const float *reduction32, float icp_thre
     *converged = c ? 1 : 0;
 }
 
-// checkPoseKernel (cpp:777-792)
-__device__ __forceinline__ bool check_pose_dev(M4 &pose, const M4 &oldPose, const float *red, unsigned W, unsigned H,
-                                               float track_threshold) {
-    if (((double)sqrtf(red[0] / red[28]) > 2e-2) || (red[28] / (W * H) < track_threshold)) {
-        pose = oldPose;
-        return false;
-    }
-    return true;
+// checkPoseKernel (cpp:777-792): the verdict; the callers replace a rejected pose by the one tracking started from
+__device__ __forceinline__ bool pose_is_good(const float *red, unsigned W, unsigned H, float track_threshold) {
+    return !(((double)sqrtf(red[0] / red[28]) > 2e-2) || (red[28] / (W * H) < track_threshold));
 }
 
 __global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction32, unsigned W, unsigned H, float thr,
                              int *ok) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    M4 p = *pose;
-    const M4 o = *oldPose;
-    float red[32];
-    for (int i = 0; i < 32; ++i) red[i] = reduction32[i];
-    *ok = check_pose_dev(p, o, red, W, H, thr) ? 1 : 0;
-    *pose = p;
+    const bool good = pose_is_good(reduction32, W, H, thr);
+    *ok = good ? 1 : 0;
+    if (!good) *pose = *oldPose;
 }
 
 // =====================================================================================
@@ -676,8 +668,9 @@ __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict
     if (ops & OP_TRACK_BEGIN) track_begin(st, track_frame, a.k);
     if (ops & OP_TRACK_END) {
         if (track_frame) {                                           // cpp:968-969
-            M4 p = st->pose;
-            bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
+            // (the pose is copied in memory only when it is rejected: a local M4 assigned on two paths is kept in an alloca,
+            // which the compiler then promotes to 64 KB of LDS - 16 floats for each of a block's 1024 possible threads)
+            bool ok = pose_is_good(st->reduction, a.width, a.height, a.track_threshold);
             // a workgroup of k_icp_tail gave up at the grid barrier during this frame's loop: the sums it went on with were
             // incomplete, so the frame counts as not tracked - old pose back, and the reduction row is marked (no inliers) so
             // that the integration gate (cpp:991) fails the same way - and the host is told (DevState::failed_frames)
@@ -686,19 +679,18 @@ __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict
                 st->timeouts_at_track_begin = now;
                 st->failed_frames += 1;
                 st->reduction[28] = 0.f;
-                p = st->oldPose;
                 ok = false;
             }
-            st->pose = p;
+            if (!ok) st->pose = st->oldPose;
             st->tracked = ok ? 1 : 0;
         } else {
             st->tracked = 0;
         }
     }
     if (ops & OP_INTEG_BEGIN) {                                      // cpp:991-1000
-        M4 p = st->pose;
-        const bool ok = check_pose_dev(p, st->oldPose, st->reduction, a.width, a.height, a.track_threshold);
-        st->pose = p;
+        const bool ok = pose_is_good(st->reduction, a.width, a.height, a.track_threshold);
+        if (!ok) st->pose = st->oldPose;
+        const M4 p = st->pose;
         const bool go = (ok && (a.frame % a.integration_rate) == 0) || (a.frame <= 3);
         st->integ.enabled = go ? 1 : 0;
         st->integrated = go ? 1 : 0;

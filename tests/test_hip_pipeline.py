@@ -184,7 +184,8 @@ def test_compute_frame_equals_phases(hip, kfmod):
     a.close(); b.close()
 
 
-def test_queued_frames_from_host_memory_equal_device_resident_input(hip, kfmod):
+@pytest.mark.parametrize("ratio", [1, 2])
+def test_queued_frames_from_host_memory_equal_device_resident_input(hip, kfmod, ratio):
     """kfh_compute_frame with a host pointer uploads the frame through a stream and two device buffers of its own, overlapped
     with the kernels queued before it; the caller may reuse its buffer as soon as the call returns (Kfusion::computeFrame's
     inputDepth, benchmark.cpp:103-104 reads every frame into the same malloc).  Same bits as frames already resident in HBM."""
@@ -194,13 +195,16 @@ def test_queued_frames_from_host_memory_equal_device_resident_input(hip, kfmod):
     k = list(s.k)
     res = (64, 64, 64)
     a, b = _make(kfmod, s, res), _make(kfmod, s, res)
-    d_all = torch.from_numpy(np.ascontiguousarray(s.depth_mm).view(np.int16)).cuda()
-    frame_bytes = s.width * s.height * 2
-    scratch = np.zeros_like(s.depth_mm[0])
+    # ratio 2: the sensor image is twice the computation size (-c 2), mm2meters subsamples it (cpp:562-589)
+    frames = np.ascontiguousarray(np.repeat(np.repeat(s.depth_mm, ratio, axis=1), ratio, axis=2))
+    in_w, in_h = s.width * ratio, s.height * ratio
+    d_all = torch.from_numpy(frames.view(np.int16)).cuda()
+    frame_bytes = in_w * in_h * 2
+    scratch = np.zeros_like(frames[0])
     for f in range(n):
-        a.compute_frame(d_all.data_ptr() + f * frame_bytes, (s.width, s.height), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
-        scratch[...] = s.depth_mm[f]
-        b.compute_frame(scratch, (s.width, s.height), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        a.compute_frame(d_all.data_ptr() + f * frame_bytes, (in_w, in_h), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        scratch[...] = frames[f]
+        b.compute_frame(scratch, (in_w, in_h), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
         scratch[...] = 0xFFFF                              # the caller's buffer is its own again
     a.synchronise(); b.synchronise()
     assert same_bits(a.get_pose(), b.get_pose())
