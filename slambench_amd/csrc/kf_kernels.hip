@@ -1146,20 +1146,34 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
     }
 }
 
+#ifndef KFH_PYR_SIDE_TEAMS
+#define KFH_PYR_SIDE_TEAMS 4
+#endif
+constexpr int PYR_SIDE_TEAMS = KFH_PYR_SIDE_TEAMS;      // tiles a side block of the pyramid job works on at a time (1, 2, 4)
 template <int NLEV>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
     __shared__ IcpShared sh;
-    __shared__ float lds[pyr_lds_floats<NLEV>()];
+    __shared__ float lds[PYR_SIDE_TEAMS][pyr_lds_floats<NLEV>()];
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
     if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
     const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
-    // all 1024 threads on one tile at a time (one pixel each at level 0): there are about as many tiles as side blocks
-    for (unsigned i = side; i < sp.count; i += nside) {
+    // A tile is a chain of barriers (load, then level by level) that lasts ~7 us however many threads work on it, so the block
+    // runs PYR_SIDE_TEAMS tiles at a time, each by a team of the size the stand-alone kernel's blocks have (same routine, same
+    // bits), instead of one tile by all 1024 threads (the launch that carries the pyramid at 1280x960: 39.5 -> 29 us; eight teams: 27 us there but
+    // +7 us at 640x480, profiles/r02_sweeps.md).  Tile i of the range goes to block
+    // i % nside, team (i / nside) % TEAMS; a team without a tile runs the routine on a tile position right of the image,
+    // which passes every barrier and writes nothing.
+    constexpr int TEAM_THREADS = ICP_THREADS / PYR_SIDE_TEAMS;
+    const int team = (int)threadIdx.x / TEAM_THREADS, tid = (int)threadIdx.x % TEAM_THREADS;
+    const unsigned rounds = (sp.count + nside * PYR_SIDE_TEAMS - 1) / (nside * PYR_SIDE_TEAMS);
+    for (unsigned r = 0; r < rounds; ++r) {
+        const unsigned i = (r * PYR_SIDE_TEAMS + (unsigned)team) * nside + side;
         const unsigned t = sp.first + i;
-        pyramid_block<NLEV, ICP_THREADS>(sp.a, lds, (int)(t % tiles_x), (int)(t / tiles_x), (int)threadIdx.x);
+        const bool active = i < sp.count;
+        pyramid_block<NLEV, TEAM_THREADS>(sp.a, lds[team], active ? (int)(t % tiles_x) : (int)tiles_x, active ? (int)(t / tiles_x) : 0, tid);
         __syncthreads();
     }
 }
