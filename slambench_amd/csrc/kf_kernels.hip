@@ -99,15 +99,24 @@ __device__ __forceinline__ float expf_glibc(float x, const double *tab /* LDS co
     return (float)y;
 }
 
+// a / d for a launch-wide constant d with r = RN(1 / d): the product plus one residual correction.  Exact (= the IEEE quotient)
+// for the divisors and numerator ranges k_verify_div has checked on this device - see there.
+__device__ __forceinline__ float div_by_const(float a, float d, float r) {
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+}
+
 constexpr int PBX = 32, PBY = 8, PR = 2;
 
 // One 32x8 output tile.  `tid` is the thread's index inside its 256-thread tile team, `active` is false for a team
 // that only keeps the barrier company (side-job rounds of the fused ICP launch, see k_icp_iter_bilateral).
-template <bool FROM_MM>
+// FD: the range term's division by 2 e_d^2 (cpp:184) in the reciprocal form, for a divisor k_verify_div has passed (numerators
+// below 2^24; a wave that meets a larger one - or a NaN - takes the IEEE division, all lanes together)
+template <bool FROM_MM, bool FD = false>
 __device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1], const double *exp_tab, int bx, int by, int tid,
                                                 bool active, float *__restrict__ floatDepth, float *__restrict__ out,
                                                 const void *__restrict__ inv, unsigned W, unsigned H, unsigned inW, int ratio,
-                                                const Gauss5 &g, float e_d_squared_2) {
+                                                const Gauss5 &g, float e_d_squared_2, float rcp_e_d_squared_2 = 0.f) {
     const int x0 = bx * PBX, y0 = by * PBY;
     constexpr int TW = PBX + 2 * PR, TH = PBY + 2 * PR;
     if (active) {
@@ -137,7 +146,10 @@ __device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1],
             const float cur = tile[ly + PR + j][lx + PR + i];
             if (cur > 0) {
                 const float mod = sq(cur - center);
-                const float factor = g.g[i + PR] * g.g[j + PR] * expf_glibc(-mod / e_d_squared_2, exp_tab);
+                float arg;
+                if (FD && __builtin_amdgcn_ballot_w64(!(mod < 0x1p24f)) == 0ull) arg = -div_by_const(mod, e_d_squared_2, rcp_e_d_squared_2);
+                else arg = -mod / e_d_squared_2;
+                const float factor = g.g[i + PR] * g.g[j + PR] * expf_glibc(arg, exp_tab);
                 t += factor * cur;
                 sum += factor;
             }
@@ -146,15 +158,15 @@ __device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1],
     out[pos] = t / sum;
 }
 
-template <bool FROM_MM>
+template <bool FROM_MM, bool FD>
 __global__ __launch_bounds__(PBX *PBY) void k_bilateral(float *__restrict__ floatDepth, float *__restrict__ out,
                                                         const void *__restrict__ inv, unsigned W, unsigned H,
-                                                        unsigned inW, int ratio, Gauss5 g, float e_d_squared_2) {
+                                                        unsigned inW, int ratio, Gauss5 g, float e_d_squared_2, float rcp) {
     __shared__ float tile[PBY + 2 * PR][PBX + 2 * PR + 1];
     __shared__ double exp_tab[32];
     const int tid = threadIdx.y * PBX + threadIdx.x;
     if (tid < 32) exp_tab[tid] = __builtin_bit_cast(double, kExp2fTable[tid]);
-    bilateral_block<FROM_MM>(tile, exp_tab, blockIdx.x, blockIdx.y, tid, true, floatDepth, out, inv, W, H, inW, ratio, g, e_d_squared_2);
+    bilateral_block<FROM_MM, FD>(tile, exp_tab, blockIdx.x, blockIdx.y, tid, true, floatDepth, out, inv, W, H, inW, ratio, g, e_d_squared_2, rcp);
 }
 
 __global__ __launch_bounds__(256) void k_mm2meters(float *__restrict__ out, unsigned W, unsigned H,
@@ -1110,7 +1122,7 @@ struct SideBilateral {
     unsigned W, H, inW;
     int ratio;
     Gauss5 g;
-    float e_d_squared_2;
+    float e_d_squared_2, rcp;
     unsigned first, count;    // range of 32x8 tiles (row-major over the tile grid) this launch covers
 };
 
@@ -1121,6 +1133,7 @@ struct SidePyramid {
 
 constexpr int SIDE_TEAMS = ICP_THREADS / 256;
 
+template <bool FD>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bilateral(IcpIterArgs a, SideBilateral sb) {
     __shared__ IcpShared sh;
     __shared__ float tiles[SIDE_TEAMS][PBY + 2 * PR][PBX + 2 * PR + 1];
@@ -1140,8 +1153,8 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
         const unsigned i = (r * SIDE_TEAMS + team) * nside + side;
         const bool active = i < sb.count;
         const unsigned t = sb.first + i;
-        bilateral_block<true>(tiles[team], exp_tab, (int)(t % tiles_x), (int)(t / tiles_x), tid, active, sb.floatDepth, sb.out, sb.in,
-                              sb.W, sb.H, sb.inW, sb.ratio, sb.g, sb.e_d_squared_2);
+        bilateral_block<true, FD>(tiles[team], exp_tab, (int)(t % tiles_x), (int)(t / tiles_x), tid, active, sb.floatDepth, sb.out, sb.in,
+                                  sb.W, sb.H, sb.inW, sb.ratio, sb.g, sb.e_d_squared_2, sb.rcp);
         __syncthreads();   // the tiles are reused by the next round
     }
 }
@@ -1489,11 +1502,6 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
 // values; negative numerators follow by symmetry, smaller ones give +-tiny either way, which the following "- 0.5f"
 // absorbs, and pos*size stays below 2^24 for every volume the launchers accept - and one mismatch keeps the IEEE division
 // for that volume (template flag FD of the view).
-__device__ __forceinline__ float div_by_const(float a, float d, float r) {
-    const float q = a * r;
-    return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
-}
-
 __global__ __launch_bounds__(256) void k_verify_div(float d, float r, unsigned long long *mismatches) {
     const unsigned long long n = 124ull << 23;   // biased exponents 27..150
     unsigned bad = 0;
@@ -2162,6 +2170,8 @@ struct WaveTrace {
     }
 };
 
+static bool divisor_verified(float d);     // (cache look-up, never a launch: see verified_divisor)
+
 unsigned icp_blocks(unsigned w, unsigned h) {
     // default 256 blocks of 1024 threads (one per CU, ~1.2 pixels per thread at 640x480); KFH_ICP_BLOCKS overrides
     static const long cap_env = [] { const char *e = getenv("KFH_ICP_BLOCKS"); const long v = e ? atol(e) : 0; return (v >= 1 && v <= (long)TR_MAX_BLOCKS) ? v : 256L; }();
@@ -2177,7 +2187,10 @@ void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_
 void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
                 const Gauss5 &g, float e_d, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
-    k_bilateral<true><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, e_d * e_d * 2); launched("k_bilateral");
+    const float d = e_d * e_d * 2;
+    if (divisor_verified(d)) k_bilateral<true, true><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, d, 1.0f / d);
+    else k_bilateral<true, false><<<grid, block, 0, s>>>(floatDepth, filtered, in, W, H, inW, ratio, g, d, 0.f);
+    launched("k_bilateral");
 }
 
 void mm2meters(float *out, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio, hipStream_t s) {
@@ -2186,7 +2199,10 @@ void mm2meters(float *out, unsigned W, unsigned H, const uint16_t *in, unsigned 
 
 void bilateral(float *out, const float *in, unsigned W, unsigned H, const Gauss5 &g, float e_d, hipStream_t s) {
     const dim3 grid((W + PBX - 1) / PBX, (H + PBY - 1) / PBY), block(PBX, PBY);
-    k_bilateral<false><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, e_d * e_d * 2); launched("k_bilateral");
+    const float d = e_d * e_d * 2;
+    if (divisor_verified(d)) k_bilateral<false, true><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, d, 1.0f / d);
+    else k_bilateral<false, false><<<grid, block, 0, s>>>(nullptr, out, in, W, H, W, 1, g, d, 0.f);
+    launched("k_bilateral");
 }
 
 void half_sample(float *out, const float *in, unsigned inW, unsigned inH, float e_d, hipStream_t s) {
@@ -2288,13 +2304,18 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
         SideBilateral sb;
         sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
         sb.inW = side->inW; sb.ratio = side->ratio; sb.g = side->gauss; sb.e_d_squared_2 = side->e_d * side->e_d * 2;
+        const bool fd = divisor_verified(sb.e_d_squared_2);
+        sb.rcp = fd ? 1.0f / sb.e_d_squared_2 : 0.f;
         sb.first = side->first; sb.count = side->count;
         unsigned extra = 0;
         if (side->ray_order) {   // the raycast dispatch sort shares the launch
             a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
             extra = 1;
         }
-        k_icp_iter_bilateral<<<nblocks + side_blocks(side->count, nblocks + extra) + extra, ICP_THREADS, 0, s>>>(a, sb); launched("k_icp_iter_bilateral");
+        const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
+        if (fd) k_icp_iter_bilateral<true><<<grid, ICP_THREADS, 0, s>>>(a, sb);
+        else k_icp_iter_bilateral<false><<<grid, ICP_THREADS, 0, s>>>(a, sb);
+        launched("k_icp_iter_bilateral");
         return;
     }
     if (side && side->kind == SideWork::PYRAMID && side->count) {
@@ -2392,10 +2413,22 @@ void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsi
 
 // Has the reciprocal form of a / d been verified for this divisor on this device (see k_verify_div)?  Cached; the check
 // takes a few milliseconds once per context (kfh_create calls prepare_volume_division).  KFH_EXACT_DIV=0 keeps IEEE.
+struct DivisorEntry { int dev; float d; bool ok; };
+static std::vector<DivisorEntry> g_divisors;
+static std::mutex g_divisors_mu;
+// what an earlier verified_divisor() of this device found; false for a divisor nobody has submitted yet (frame-path launchers
+// ask this one: it never launches or waits)
+static bool divisor_verified(float d) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_divisors_mu);
+    for (const DivisorEntry &e : g_divisors) if (e.dev == dev && e.d == d) return e.ok;
+    return false;
+}
 static bool verified_divisor(float d, hipStream_t s) {
-    struct Entry { int dev; float d; bool ok; };
-    static std::vector<Entry> cache;
-    static std::mutex mu;
+    typedef DivisorEntry Entry;
+    std::vector<Entry> &cache = g_divisors;
+    std::mutex &mu = g_divisors_mu;
     static const bool allow = [] { const char *e = getenv("KFH_EXACT_DIV"); return !(e && e[0] == '0'); }();
     int dev = 0;
     hipGetDevice(&dev);
@@ -2423,6 +2456,8 @@ static bool fast_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStre
 }
 
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) { (void)fast_division(dim, sx, sy, sz, s); }
+// the bilateral filter's range divisor 2 e_d^2 (its numerators, squared depth differences, stay far below 2^24 for depth in metres)
+void prepare_bilateral_division(float e_d, hipStream_t s) { (void)verified_divisor(e_d * e_d * 2, s); }
 
 static int ray_group() {   // lanes per ray (KFH_RAY_GROUP = 1, 2, 4, 8)
     static const long g = env_long("KFH_RAY_GROUP", 1, 8, 4);

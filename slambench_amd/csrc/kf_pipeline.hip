@@ -718,6 +718,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     c->viewPose = pose;
     kfh_reset(c);
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
+    launch::prepare_bilateral_division(e_delta, c->stream);
     if (getenv("KERNEL_TIMINGS")) { c->kernel_timings = true; c->prof_mask = (1u << KFH_PROF_COUNT) - 1u; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     {
@@ -1200,6 +1201,7 @@ int kfh_k_mm2meters(float *out, uint32_t out_w, uint32_t out_h, const uint16_t *
 
 void kfh_k_bilateral_filter(float *out, const float *in, uint32_t w, uint32_t h, const float *g5, float e_d, int32_t r, void *stream) {
     if (r != radius) { g_last_error = "bilateral radius must be 2"; return; }
+    launch::prepare_bilateral_division(e_d, (hipStream_t)stream);
     launch::bilateral(out, in, w, h, load_gauss(g5), e_d, (hipStream_t)stream);
 }
 
@@ -1207,6 +1209,7 @@ int kfh_k_preprocess(float *float_depth, float *filtered, uint32_t w, uint32_t h
                      const float *g5, float e_d, void *stream) {
     const int r = ratio_of(w, h, in_w, in_h);
     if (r < 0) return KFH_ERR_INVALID_RATIO;
+    launch::prepare_bilateral_division(e_d, (hipStream_t)stream);
     launch::preprocess(float_depth, filtered, w, h, in, in_w, r, load_gauss(g5), e_d, (hipStream_t)stream);
     return KFH_OK;
 }
