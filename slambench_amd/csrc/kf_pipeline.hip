@@ -349,7 +349,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     if (!pyramid_ready) enqueue_pyramid(c, k);
     // side-job plan.  A side block costs what its CU's share of tiles costs (~2.3 us per 32x8 bilateral tile team round,
     // ~8 us of latency for a pyramid tile), and the launch lasts as long as its slowest block, so: the bilateral filter
-    // is split over TWO launches (2.5 tiles per idle CU each, shorter than the ICP iteration it rides on), the pyramid
+    // is split over TWO or THREE launches (shorter than the ICP iteration it rides on at 640x480; VALU-bound and longer at 1280x960), the pyramid
     // takes one, and all three go on launches that are long anyway - executed iterations with a solve in front of them
     // (iteration 0 of a frame has none and is short; late iterations of a level are usually skipped).
     int coarse_launches = 0;
@@ -360,7 +360,8 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         const int first_l1 = c->iterations[L - 1] > 0 ? c->iterations[L - 1] : 0;    // first launch of the second-coarsest level
         if (!bil_env.empty() && (!next->pyramid || !pyr_env.empty())) { bil_its = bil_env; if (next->pyramid) pyr_its = pyr_env; }
         else if (next->pyramid) {
-            if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
+            if (coarse_launches >= 6 && first_l1 >= 4 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2, 3}; pyr_its = {first_l1 + 1}; }   // (1280x960: 233.7 -> 227.2 us per loop against two launches, 640x480 the same)
+            else if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
             else if (coarse_launches >= 3) { bil_its = {0, 1}; pyr_its = {2}; }
             else if (coarse_launches == 2) { bil_its = {0}; pyr_its = {1}; }
         } else if (coarse_launches >= 3) bil_its = {1, 2};
