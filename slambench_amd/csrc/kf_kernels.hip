@@ -146,10 +146,16 @@ __device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1],
             const float cur = tile[ly + PR + j][lx + PR + i];
             if (cur > 0) {
                 const float mod = sq(cur - center);
-                float arg;
-                if (FD && __builtin_amdgcn_ballot_w64(!(mod < 0x1p24f)) == 0ull) arg = -div_by_const(mod, e_d_squared_2, rcp_e_d_squared_2);
-                else arg = -mod / e_d_squared_2;
-                const float factor = g.g[i + PR] * g.g[j + PR] * expf_glibc(arg, exp_tab);
+                float e;
+                if (i == 0 && j == 0 && __builtin_amdgcn_ballot_w64(!(mod == 0.f)) == 0ull) {
+                    e = 1.0f;      // the centre tap: mod = +0 (unless the depth is infinite), the argument -0, and expf(-0) is exactly 1
+                } else {
+                    float arg;
+                    if (FD && __builtin_amdgcn_ballot_w64(!(mod < 0x1p24f)) == 0ull) arg = -div_by_const(mod, e_d_squared_2, rcp_e_d_squared_2);
+                    else arg = -mod / e_d_squared_2;
+                    e = expf_glibc(arg, exp_tab);
+                }
+                const float factor = g.g[i + PR] * g.g[j + PR] * e;
                 t += factor * cur;
                 sum += factor;
             }
