@@ -1272,6 +1272,9 @@ template <bool KZ> __device__ __forceinline__ void march_step(ColumnState &S, v2
 }
 template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) { return KZ ? S.b.x : S.cz; }
 
+#ifndef KFH_INT_PROBE_NO_REPLAY
+#define KFH_INT_PROBE_NO_REPLAY 0
+#endif
 #ifndef KFH_INT_IDLE_EXIT
 #define KFH_INT_IDLE_EXIT 1
 #endif
@@ -1350,13 +1353,17 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             chunk_out = chunk_out || behind;
         }
-        if (!chunk_out && (dbg & 16)) {   // (timing probe: the state at z0 from one multiply-add per sum - right to a few ulps, not to the bit)
+#if KFH_INT_PROBE_NO_REPLAY      // timing probe (a build flag: the extra path costs the kept kernel a register spill): the state at z0 from
+        if (!chunk_out) {        // one multiply-add per sum - right to a few ulps, not to the bit (profiles/r02_sweeps.md)
             const float zf = (float)z0;
             S.a.x = __builtin_fmaf(zf, da.x, S.a.x); S.a.y = __builtin_fmaf(zf, da.y, S.a.y);
             S.b.x = __builtin_fmaf(zf, db.x, S.b.x); S.b.y = __builtin_fmaf(zf, db.y, S.b.y);
             S.cy = __builtin_fmaf(zf, dc.x, S.cy); S.cz = __builtin_fmaf(zf, dc.y, S.cz);
-        } else if (!chunk_out)
+        }
+#else
+        if (!chunk_out)
         for (unsigned z = 0; z < z0; ++z) { march_step<KZ>(S, da, db, dc); }
+#endif
         const size_t plane = (size_t)sx * sy;
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -2523,8 +2530,8 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
                unsigned *block_order, unsigned *block_cost, bool k_trivial, hipStream_t s) {
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
     // timing probes (results are wrong with them): 1 every batch rejected, 2 stop after the projection pass, 4 stop after the depth
-    // classification, 8 no whole-chunk reject, 16 no replay (approximate start states); KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
-    static const int dbg_env = (int)env_long("KFH_INTEGRATE_DBG", 0, 31, 0);
+    // classification, 8 no whole-chunk reject; KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
+    static const int dbg_env = (int)env_long("KFH_INTEGRATE_DBG", 0, 15, 0);
     static const long dbg_from = env_long("KFH_INTEGRATE_DBG_FROM", 0, 1000000, 0);
     static std::atomic<long> n_launch{0};
     const int dbg = (dbg_env && n_launch.fetch_add(1) >= dbg_from) ? dbg_env : 0;
