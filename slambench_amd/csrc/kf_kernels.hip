@@ -2477,9 +2477,16 @@ void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipS
 // the bilateral filter's range divisor 2 e_d^2 (its numerators, squared depth differences, stay far below 2^24 for depth in metres)
 void prepare_bilateral_division(float e_d, hipStream_t s) { (void)verified_divisor(e_d * e_d * 2, s); }
 
-static int ray_group() {   // lanes per ray (KFH_RAY_GROUP = 1, 2, 4, 8)
-    static const long g = env_long("KFH_RAY_GROUP", 1, 8, 4);
-    return (g == 1 || g == 2 || g == 8) ? (int)g : 4;
+// Lanes that march one ray together (cast_ray_group).  Sharing a ray shortens the serial chain per ray but leaves lanes with
+// discarded samples and a redundant preamble; it pays while there are too few rays to fill the chip with waves of their own.
+// k_raycast at 256^3, us for 4 / 2 / 1 lanes per ray (profiles/r02_ray_group_sizes.txt): 320x240 31 / 47 / 60, 640x480 52 / 54 / 66,
+// 800x600 73 / 64 / 71, 960x720 103 / 81 / 71, 1280x960 165 / 122 / 91 - so the group size follows the ray count unless
+// KFH_RAY_GROUP = 1, 2, 4, 8 fixes it.  Every size gives the same bits (tests/test_hip_fullsize.py).
+static int ray_group(unsigned W, unsigned H) {
+    static const long g = env_long("KFH_RAY_GROUP", 0, 8, 0);
+    if (g == 1 || g == 2 || g == 4 || g == 8) return (int)g;
+    const unsigned long long rays = (unsigned long long)W * H;
+    return rays >= 600000ull ? 1 : (rays >= 400000ull ? 2 : 4);
 }
 static dim3 ray_grid(int q, unsigned W, unsigned H) {
     const unsigned rw = (q <= 2) ? 8 : 4, rh = (64 / q) / rw;
@@ -2569,19 +2576,19 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
     }
     if (ray_reorder_enabled() && tile_order && tile_cost) { sg.order = tile_order; sg.cost = tile_cost; }
     static WaveTrace wt("KFH_RAY_TRACE");
-    const dim3 tg = raycast_launch_grid(ray_group(), W, H), td = ray_tile_dim(ray_group(), W, H);
+    const dim3 tg = raycast_launch_grid(ray_group(W, H), W, H), td = ray_tile_dim(ray_group(W, H), W, H);
     sg.tiles_x = td.x; sg.tiles_y = td.y;
     sg.trace = wt.arm((size_t)tg.x * tg.y * KFH_RAY_BLOCK_WAVES, s);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
-        switch (ray_group()) {
+        switch (ray_group(W, H)) {
         case 1: k_raycast<1, 1><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         case 2: k_raycast<2, 1><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         case 8: k_raycast<8, 1><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         default: k_raycast<4, 1><<<raycast_launch_grid(4, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         }
     } else {
-        switch (ray_group()) {
+        switch (ray_group(W, H)) {
         case 1: k_raycast<1, 0><<<raycast_launch_grid(1, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         case 2: k_raycast<2, 0><<<raycast_launch_grid(2, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
         case 8: k_raycast<8, 0><<<raycast_launch_grid(8, W, H), RAY_BLOCK, 0, s>>>(vertex, normal, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, sg, rdim); launched("k_raycast"); break;
@@ -2592,13 +2599,13 @@ void raycast(float4 *vertex, float4 *normal, unsigned W, unsigned H, const int16
 }
 
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s) {
-    const dim3 tg = ray_tile_dim(ray_group(), W, H);
+    const dim3 tg = ray_tile_dim(ray_group(W, H), W, H);
     k_ray_order<<<1, 1024, 0, s>>>(tile_order, tile_cost, tg.x, tg.y, 0u); launched("k_ray_order");
 }
-void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_tile_dim(ray_group(), W, H); *tx = g.x; *ty = g.y; }
+void ray_tile_grid(unsigned W, unsigned H, unsigned *tx, unsigned *ty) { const dim3 g = ray_tile_dim(ray_group(W, H), W, H); *tx = g.x; *ty = g.y; }
 bool ray_reorder_enabled() { static const bool on = [] { const char *e = getenv("KFH_RAY_REORDER"); return !(e && e[0] == '0'); }(); return on; }
 
-unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_tile_dim(ray_group(), W, H); return g.x * g.y; }
+unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_tile_dim(ray_group(W, H), W, H); return g.x * g.y; }
 
 __global__ void k_iota(unsigned *p, unsigned n) {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
@@ -2623,14 +2630,14 @@ void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsi
     const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     if (fast_division(dim, sx, sy, sz, s)) {
-        switch (ray_group()) {
+        switch (ray_group(W, H)) {
         case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         }
     } else {
-        switch (ray_group()) {
+        switch (ray_group(W, H)) {
         case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
         case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
