@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput bench of the KinectFusion hot path on MI355X (contract: see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N > 1: under torch.distributed.run - or plainly: bench.py then
+                                                             starts the N ranks itself as a child torch.distributed.run)
     python bench.py --raw living_room_traj2_loop.raw --gt livingRoom2.gt.freiburg      (real ICL-NUIM data, when present;
                                                              or KFH_ICL_NUIM_DIR=<dir holding the Makefile's file names>)
 
@@ -14,6 +15,9 @@ synthetic stream (no dataset offline) already resident in HBM when the timed reg
 (frames shard by stream; no data-path collective) and RCCL is used only for the barriers and one all-reduce.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  n_gpus / ranks_seen         the world size of the process group and an all-reduce of ones over it (RCCL saw that many ranks)
+  configs                     compact legs of BASELINE configs[2] (cfg3) and configs[3] (cfg4) of the same run: value, ms_per_step,
+                              value_host_input, roofline of integrate / raycast / the ICP loop with traffic and traffic_source
   roofline / roofline_other   icp loop, k_integrate, k_raycast: algorithmic bytes / HIP-event time measured in this run
   cpu_baseline                the OpenMP oracle timed on the host cores on a bounded prefix of the same stream
   fps_total                   the same queued loop plus the three renders and their read-back
@@ -63,7 +67,7 @@ def icp_launches(pyramid, head=4):
     return n + (0 if closed else 1)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -83,15 +87,39 @@ def parse():
                          "steps/10 clamped to 1..8; 0 = none")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent RGB-D streams processed concurrently on each GPU (throughput mode; the headline is 1)")
-    return ap.parse_args()
+    ap.add_argument("--extra-configs", default=None,
+                    help="comma list of configurations measured as compact legs after the headline and reported under \"configs\" "
+                         "(default: cfg3,cfg4 when the headline is cfg2, else none; \"none\" = none)")
+    ap.add_argument("--extra-steps", type=int, default=40, help="timed frames of a compact leg (warm-up: 8)")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="rehearsal of the N-rank plumbing without a GPU: rendezvous, barriers, all-reduces and the JSON line are real, "
+                         "the frames are not run (value is null, \"dry_run\": true); used by tests/test_bench_ranks.py")
+    return ap.parse_args(argv)
 
 
-def load_workload(args, rank, n_frames, W, H):
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` launched plainly: start the N ranks as a CHILD `torch.distributed.run` and relay its output and exit
+    code.  Called before anything in this process has touched torch or the GPU (a process that has must never exec another)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: --gpus %d without a torch.distributed environment: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def load_workload(args, rank, n_frames, W, H, real_ok=True):
     """The depth stream of this rank and the scene parameters that go with it.  Returns a namespace with depth_mm (n, H, W)
     uint16, k, init_pos, volume_size, gt_rows (or None), data label, and the trajectory record when the data is real."""
     from slambench_amd import checkpos, multi, rawio, synth, trajectories
-    raw, gt = args.raw, args.gt
-    if raw is None:
+    raw, gt = (args.raw, args.gt) if real_ok else (None, None)
+    if raw is None and real_ok:
         idx = args.traj if args.traj is not None else (2 if multi.env_rank()[0] == 1 else rank % multi.N_TRAJECTORIES)
         found = trajectories.find_dataset(None, idx)
         if found:
@@ -106,7 +134,7 @@ def load_workload(args, rank, n_frames, W, H):
     t = trajectories.TRAJECTORIES[idx]
     reader = rawio.RawDepthReader(raw) if os.path.isfile(raw) else rawio.SceneDepthReader(raw)
     if tuple(reader.get_input_size()) != (W, H):
-        raise SystemExit("--raw holds %dx%d frames, config %s needs %dx%d" % (*reader.get_input_size(), args.config, W, H))
+        raise SystemExit("--raw holds %dx%d frames, this configuration needs %dx%d" % (*reader.get_input_size(), W, H))
     frames = []
     while len(frames) < n_frames:
         d = reader.read_next_depth_frame()
@@ -157,7 +185,32 @@ class Leg:
             ctx.close()
 
 
-def timed_run(make_leg, torch, dist, multi, n_warm, n_steps, prof_every, coll_device):
+class DryLeg:
+    """--dry-collectives: the frames are not run; everything around them (collectives, timing brackets, JSON) is."""
+    kf, with_renders = None, True
+
+    def step(self, f):
+        pass
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class Session:
+    """What every leg of a run shares: the process group (or None), this rank, the device the collectives run on."""
+
+    def __init__(self, torch, dist, world, rank, local_rank, coll_device, dry):
+        self.torch, self.dist, self.world, self.rank, self.local_rank, self.coll_device, self.dry = torch, dist, world, rank, local_rank, coll_device, dry
+
+    def device_sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+
+def timed_run(S, make_leg, multi, n_warm, n_steps, prof_every):
     """Warm up on frames [0, n_warm), time frames [n_warm, n_warm + n_steps) between barrier + synchronize pairs.
     A rank that fails still takes part in every collective, so the job ends with the reason instead of a watchdog kill."""
     leg, err = None, None
@@ -170,13 +223,13 @@ def timed_run(make_leg, torch, dist, multi, n_warm, n_steps, prof_every, coll_de
             leg.kf.set_profiling(["icp", "integrate", "raycast"], every=prof_every, rotate=True)
     except Exception as e:       # noqa: BLE001
         err = e
-    if not multi.all_ok(err is None, dist, coll_device):
+    if not multi.all_ok(err is None, S.dist, S.coll_device):
         if err is not None:
-            print("bench.py: rank %d failed before the timed region: %r" % (multi.env_rank()[1], err), file=sys.stderr)
+            print("bench.py: rank %d failed before the timed region: %r" % (S.rank, err), file=sys.stderr)
         raise SystemExit(1)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    S.device_sync()
+    if S.dist is not None:
+        S.dist.barrier()
     t0 = time.perf_counter()
     try:
         for f in range(n_warm, n_warm + n_steps):
@@ -184,18 +237,14 @@ def timed_run(make_leg, torch, dist, multi, n_warm, n_steps, prof_every, coll_de
         leg.sync()
     except Exception as e:       # noqa: BLE001
         err = e
-    torch.cuda.synchronize()
+    S.device_sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
+    if S.dist is not None:
+        S.dist.barrier()
     return elapsed, leg, err
 
 
-def cpu_baseline(wl, cfg, budget_s, max_frames, min_frames=8):
-    """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only); then V of
-    SURVEY §8(d) - the distinct voxels one raycast samples - counted by the oracle on the V_FRAMES frames that follow the prefix."""
-    from oracle import orc
-    orc.build()
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # cgroup CPU quota of the box (a one-GPU share is 16 CPUs)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -203,6 +252,15 @@ def cpu_baseline(wl, cfg, budget_s, max_frames, min_frames=8):
             cores = max(1, min(cores, int(float(q) / float(per))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(wl, cfg, budget_s, max_frames, min_frames=8):
+    """OpenMP oracle on the host cores over a bounded prefix of the same stream (computation column only); then V of
+    SURVEY §8(d) - the distinct voxels one raycast samples - counted by the oracle on the V_FRAMES frames that follow the prefix."""
+    from oracle import orc
+    orc.build()
+    cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     W, H, vres, pyramid, irate, _ = cfg
     k = list(wl.k)
@@ -271,143 +329,83 @@ def host_buffers_leg(wl, cfg, n_frames):
             shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched plainly with --gpus N: this process has made no torch / GPU call; the ranks run in a child process
+        raise SystemExit(spawn_ranks(args, argv))
+
     import torch
-    from slambench_amd import checkpos, kfusion, multi
+    from slambench_amd import multi
 
     world, rank, local_rank = multi.env_rank()
+    if world != args.gpus:
+        # never measure fewer GPUs than were asked for (nor more): the record would carry the wrong n_gpus
+        print("bench.py: --gpus %d but the torch.distributed environment holds WORLD_SIZE=%d: start it as `python bench.py --gpus %d` "
+              "or `python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus, args.gpus), file=sys.stderr)
+        raise SystemExit(2)
+    dry = args.dry_collectives
+    backend = "gloo" if dry else os.environ.get("KFH_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("KFH_BENCH_ONE_DEVICE") == "1"     # rehearsal on a one-GPU box: the ranks side by side on cuda:0, collectives on the host
+    if not dry:
+        have = torch.cuda.device_count()
+        need = 1 if one_device else world
+        if have < need:
+            print("bench.py: rank %d: --gpus %d needs %d visible GPU(s), this node shows %d" % (rank, args.gpus, need, have), file=sys.stderr)
+            raise SystemExit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # rehearsal on a one-GPU box: KFH_BENCH_BACKEND=gloo KFH_BENCH_ONE_DEVICE=1 runs the ranks side by side on cuda:0
-        # with the collective on the host (RCCL refuses two ranks on one device); the driver's runs use neither
-        backend = os.environ.get("KFH_BENCH_BACKEND", "nccl")
-        if os.environ.get("KFH_BENCH_ONE_DEVICE") == "1":
+        if one_device:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
+        if not dry:
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist_mod.init_process_group(backend)
         dist = dist_mod
-    else:
+    elif not dry:
         torch.cuda.set_device(0)
         local_rank = 0
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    coll_device = "cuda" if (dist is None or os.environ.get("KFH_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
+    coll_device = "cuda" if (backend == "nccl" and not dry) else "cpu"
+    S = Session(torch, dist, world, rank, local_rank, coll_device, dry)
     try:
-        run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusion, multi)
+        run(S, args, multi)
     finally:
         if dist is not None:
             dist.destroy_process_group()
 
 
-def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusion, multi):
-    cfg = CONFIGS[args.config]
-    if os.environ.get("KFH_DEBUG_PYRAMID"):    # experiments only (cost of the queued-but-empty ICP launches)
-        cfg = cfg[:3] + (tuple(int(v) for v in os.environ["KFH_DEBUG_PYRAMID"].split(",")),) + cfg[4:]
-    W, H, vres, pyramid, irate, zrate = cfg
-    n_frames = args.warmup + args.steps
-    prof_every = args.profile_every if args.profile_every is not None else max(1, min(8, args.steps // 10))
-    while prof_every > 1 and math.gcd(prof_every, irate) != 1:     # integrate runs on frames = 0 (mod -r): the sampled frames must meet them
-        prof_every += 1
-    # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
-    # (the CPU baseline wants ~15 s of work whatever --steps is: a synthetic stream is generated long enough for it; the GPU
-    # legs use its first warmup + steps frames)
-    cpu_frames = 150 if (world == 1 and not args.no_cpu_baseline and args.raw is None) else 0
-    wl = load_workload(args, rank, max(n_frames, cpu_frames) + V_FRAMES, W, H)
-    d_depth = torch.from_numpy(wl.depth_mm.view(np.int16)).cuda()
-
-    # The secondary leg (the same loop plus the three renders and their read-back) runs FIRST: it is a measurement of its own
-    # and leaves the device at its working clocks for the headline leg, which otherwise starts from an idle-clocked GPU and,
-    # at the 25 frames of a `--steps 20 --warmup 5` run, ends before the clocks have settled.
-    fps_total = None
-    if not args.no_total:
-        e2, leg2, err2 = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, True), torch, dist, multi, args.warmup, args.steps, 0, coll_device)
-        if leg2 is not None:
-            leg2.close()
-        j2 = multi.aggregate(multi.RankStats(args.steps, e2, failed=0 if err2 is None else 1), dist, device=coll_device)
-        fps_total = None if j2.failed else j2.fps
-
-    # ... and the queued loop fed from pageable host memory (PCIe-inclusive; never the headline value)
-    fps_host_input = None
-    if not args.no_total:
-        e3, leg3, err3 = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, host_input=True), torch, dist, multi, args.warmup, args.steps, 0, coll_device)
-        if leg3 is not None:
-            leg3.close()
-        j3 = multi.aggregate(multi.RankStats(args.steps, e3, failed=0 if err3 is None else 1), dist, device=coll_device)
-        fps_host_input = None if j3.failed else j3.fps
-
-    spg = max(1, args.streams_per_gpu)
-    elapsed, leg, err = timed_run(lambda: Leg(kfusion, wl, d_depth, cfg, local_rank, False, spg - 1, host_input=args.host_input), torch, dist, multi,
-                                  args.warmup, args.steps, prof_every, coll_device)
-    failed, errs = 0, [0.0]
-    prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = None
-    try:
-        if err is not None:
-            raise err
-        kf = leg.kf
-        prof = kf.read_profile()
-        updated = kf.integrate_updated()
-        icp_iters = kf.icp_iterations()
-        icp_by_level = kf.icp_level_iterations()
-        if kf.barrier_timeouts():
-            raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
-        fallbacks = kf.solve_fallbacks()
-        poses, tracked, integrated = kf.frame_log(n_frames)
-        leg.close()
-        # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
-        if wl.gt_rows is not None:
-            pos_after = poses[:, :3, 3] - wl.init_pos.astype(np.float32)
-            rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
-            errs = checkpos.ate([tuple(r) for r in rows], wl.gt_rows)
-    except Exception as e:       # noqa: BLE001
-        failed = 1
-        print("bench.py: rank %d failed: %r" % (rank, e), file=sys.stderr)
-
-    # whole-job aggregate: frames summed over ranks / max time over ranks (one small all-reduce on RCCL)
-    job = multi.aggregate(multi.RankStats(args.steps * spg, elapsed, float(np.sum(errs)), float(np.max(errs)),
-                                          0 if tracked is None else int((tracked == 0).sum()), failed), dist, device=coll_device)
-    if job.failed:
-        raise SystemExit("bench.py: %d rank(s) failed - no result" % job.failed)
-    t_max, total_frames = job.seconds, job.frames
-    ate = None if wl.gt_rows is None else {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs),
-                                           "untracked_all_ranks": job.untracked}
-
-    if rank != 0:
-        return
-
-    cpu, v_distinct = (None, None)
-    if not args.no_cpu_baseline and world == 1:
-        cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, wl.depth_mm.shape[0])
-    elif not args.no_cpu_baseline:
-        # N > 1: no CPU baseline (rank 0 at N = 1 only), but raycast's algorithmic bytes still need V: the oracle runs just far
-        # enough to have a surface to cast at (6 frames) and counts on the two that follow
-        _, v_distinct = cpu_baseline(wl, cfg, 0.0, min(n_frames + V_FRAMES, 6 + V_FRAMES), min_frames=6)
-    host = None
-    if not args.no_host_buffers and world == 1:
-        del d_depth
-        torch.cuda.empty_cache()
-        host = host_buffers_leg(wl, cfg, n_frames)
-
-    # HBM bytes per launch from the PMC passes of profiles/collect_traffic.sh (rocprofv3 cannot wrap this process from
-    # inside); null when no measurement of this configuration is committed
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+def traffic_of(config):
+    """HBM bytes per launch from the PMC passes of profiles/collect_traffic.sh (rocprofv3 cannot wrap this process from inside): read
+    from the committed summary of this configuration, NOT measured in this run - `traffic_source` in the line says so."""
+    traffic, source = {}, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         for kname, v in tj.items():
             for short in ("integrate", "raycast"):
                 if ("k_" + short) in kname:
                     traffic[short] = v["hbm_bytes_per_launch"]
-        # the ICP loop of a frame = all k_icp_iter* / k_icp_tail / k_icp_final launches (+ k_control when it is a launch of
-        # its own); frames of the run = launches of k_raycast (one per frame)
+        # the ICP loop of a frame = all k_icp* launches (+ k_control when it is a launch of its own); frames of the run =
+        # launches of k_raycast (one per frame)
         frames_t = sum(v["launches"] for kname, v in tj.items() if "k_raycast" in kname)
         loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
         if frames_t and loop_t:
             traffic["icp"] = round(loop_t / frames_t)
+        source = "profiles/traffic_%s.json: committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, profiles/collect_traffic.sh) of the same command, not measured in this run" % config
+    return traffic, source
+
+
+def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct):
+    """roofline entries of k_integrate, k_raycast and the ICP loop: algorithmic bytes / HIP-event time of this run"""
+    W, H, vres, pyramid, irate, zrate = cfg
+    traffic, source = traffic_of(config_name)
     P = W * H
     roof = {}
     for name in ("integrate", "raycast"):
@@ -428,7 +426,8 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
             detail = {"V_distinct_voxels_sampled": round(v_distinct)}
         gbs = alg / avg_s / 1e9
         roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                      "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic.get(name), "traffic_source": source if traffic.get(name) else None,
+                      "avg_us": round(avg_s * 1e6, 2), "launches": n,
                       "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg), **detail}
     # The ICP loop of a frame (k_icp_iter* launches, k_icp_tail for the late iterations of a level, k_icp_final): 48 + 4 bytes per associated pixel
     # for every EXECUTED iteration (below), plus - on the queued-frame path - the
@@ -447,29 +446,195 @@ def run(args, torch, dist, world, rank, local_rank, coll_device, checkpos, kfusi
         gbs = alg / avg_s / 1e9
         roof["icp"] = {"kernel": "k_icp_iter* + k_icp_tail (one frame's ICP loop: %d queued iterations in %d launches)" % (sum(pyramid), icp_launches(pyramid)), "bound": "hbm",
                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                       "traffic": traffic.get("icp"), "avg_us": round(avg_s * 1e6, 2), "launches": n,
+                       "traffic": traffic.get("icp"), "traffic_source": source if traffic.get("icp") else None, "avg_us": round(avg_s * 1e6, 2), "launches": n,
                        "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg),
                        "of_which_next_frame_preprocessing_bytes": round(alg_pre),
                        "executed_iterations_per_frame_by_level": [round(v / max(1, n_frames), 2) for v in icp_by_level]}
+    return roof
+
+
+def workload_string(name, cfg, wl):
+    W, H, vres, pyramid, irate, zrate = cfg
+    return ("%s: %dx%d depth, -c 1 -v %d -y %s -r %d -z %d -s %g -p %s -k %s -m 0.1, one stream per GPU"
+            % (name, W, H, vres, ",".join(map(str, pyramid)), irate, zrate, wl.volume_size,
+               ",".join("%g" % v for v in wl.init_factors), ",".join("%g" % v for v in wl.k)))
+
+
+def measure(S, args, multi, config_name, steps, warmup, full):
+    """One configuration: the queued loop with device-resident input (timed with sampled HIP-event pairs for the rooflines), the same
+    loop fed from pageable host memory, and - `full` only - the loop with the three renders, the drop-in driver and the CPU baseline.
+    Every rank runs every leg (the collectives must match); rank 0 returns the result dictionary, the others None."""
+    from slambench_amd import checkpos
+    torch, dist = S.torch, S.dist
+    cfg = CONFIGS[config_name]
+    if full and os.environ.get("KFH_DEBUG_PYRAMID"):    # experiments only (cost of the queued-but-empty ICP launches)
+        cfg = cfg[:3] + (tuple(int(v) for v in os.environ["KFH_DEBUG_PYRAMID"].split(",")),) + cfg[4:]
+    W, H, vres, pyramid, irate, zrate = cfg
+    n_frames = warmup + steps
+    prof_every = args.profile_every if args.profile_every is not None else max(1, min(8, steps // 10))
+    while prof_every > 1 and math.gcd(prof_every, irate) != 1:     # integrate runs on frames = 0 (mod -r): the sampled frames must meet them
+        prof_every += 1
+    spg = max(1, args.streams_per_gpu) if full else 1
+
+    if S.dry:
+        mk = lambda *a, **kw: DryLeg()
+        wl = d_depth = kfusion = None
+    else:
+        from slambench_amd import kfusion
+        # one independent RGB-D stream per GPU: 4 distinct trajectories, reused x2 on 8 GPUs (BASELINE configs[4])
+        # (the CPU baseline wants ~15 s of work whatever --steps is: a synthetic stream is generated long enough for it; the GPU
+        # legs use its first warmup + steps frames)
+        cpu_frames = 150 if (full and S.world == 1 and not args.no_cpu_baseline and args.raw is None) else 0
+        wl = load_workload(args, S.rank, max(n_frames, cpu_frames) + V_FRAMES, W, H, real_ok=(W, H) == CONFIGS[args.config][:2])
+        d_depth = torch.from_numpy(wl.depth_mm.view(np.int16)).cuda()
+        mk = lambda renders, extra=0, host_input=False: Leg(kfusion, wl, d_depth, cfg, S.local_rank, renders, extra, host_input)
+
+    def secondary(make, what):
+        """a leg whose only product is its whole-job rate; a failure is reported (stderr and the line), never silent"""
+        e, leg, err = timed_run(S, make, multi, warmup, steps, 0)
+        if leg is not None:
+            leg.close()
+        if err is not None:
+            print("bench.py: rank %d: the %s leg of %s failed: %r" % (S.rank, what, config_name, err), file=sys.stderr)
+        j = multi.aggregate(multi.RankStats(steps, e, failed=0 if err is None else 1), dist, device=S.coll_device)
+        return (None, "%d rank(s) failed%s" % (j.failed, ": %r" % (err,) if err is not None else "")) if j.failed else (j.fps, None)
+
+    # The secondary legs run FIRST: each is a measurement of its own and leaves the device at its working clocks for the headline
+    # leg, which otherwise starts from an idle-clocked GPU and, at the 25 frames of a `--steps 20 --warmup 5` run, ends before the
+    # clocks have settled.
+    fps_total = fps_total_error = None
+    if full and not args.no_total:      # the same loop plus the three renders and their read-back
+        fps_total, fps_total_error = secondary(lambda: mk(True), "render")
+    fps_host_input = fps_host_input_error = None
+    if not (full and args.no_total):    # the queued loop fed from pageable host memory (PCIe inside the loop; never `value`)
+        fps_host_input, fps_host_input_error = secondary(lambda: mk(False, host_input=True), "host-input")
+
+    elapsed, leg, err = timed_run(S, lambda: mk(False, spg - 1, host_input=full and args.host_input), multi, warmup, steps, prof_every)
+    failed, errs = 0, [0.0]
+    prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = None
+    try:
+        if err is not None:
+            raise err
+        if not S.dry:
+            kf = leg.kf
+            prof = kf.read_profile()
+            updated = kf.integrate_updated()
+            icp_iters = kf.icp_iterations()
+            icp_by_level = kf.icp_level_iterations()
+            if kf.barrier_timeouts():
+                raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
+            fallbacks = kf.solve_fallbacks()
+            poses, tracked, integrated = kf.frame_log(n_frames)
+            leg.close()
+            # ATE exactly as checkPos.py scores a log: row n holds the position before frame n (benchmark.cpp:127-131)
+            if wl.gt_rows is not None:
+                pos_after = poses[:, :3, 3] - wl.init_pos.astype(np.float32)
+                rows = np.vstack([np.zeros((1, 3), np.float32), pos_after[:-1]])
+                errs = checkpos.ate([tuple(r) for r in rows], wl.gt_rows)
+    except Exception as e:       # noqa: BLE001
+        failed = 1
+        print("bench.py: rank %d failed (%s): %r" % (S.rank, config_name, e), file=sys.stderr)
+
+    # whole-job aggregate: frames summed over ranks / max time over ranks (one small all-reduce on RCCL)
+    job = multi.aggregate(multi.RankStats(steps * spg, elapsed, float(np.sum(errs)), float(np.max(errs)),
+                                          0 if tracked is None else int((tracked == 0).sum()), failed), dist, device=S.coll_device)
+    if job.failed:
+        raise SystemExit("bench.py: %d rank(s) failed - no result" % job.failed)
+    t_max, total_frames = job.seconds, job.frames
+    if S.rank != 0:
+        return None
+    if S.dry:
+        return {"value": None, "ms_per_step": None, "timed_s": round(t_max, 6), "frames": total_frames, "dry_run": True}
+
+    ate = None if wl.gt_rows is None else {"mean": float(np.mean(errs)), "max": job.ate_max, "frames_rank0": len(errs),
+                                           "untracked_all_ranks": job.untracked}
+    cpu, v_distinct = (None, None)
+    if full and not args.no_cpu_baseline and S.world == 1:
+        cpu, v_distinct = cpu_baseline(wl, cfg, args.cpu_seconds, wl.depth_mm.shape[0])
+    elif not args.no_cpu_baseline:
+        # no CPU baseline here (rank 0 at N = 1, headline configuration only), but raycast's algorithmic bytes still need V: the oracle
+        # runs just far enough to have a surface to cast at (6 frames) and counts on the two that follow
+        _, v_distinct = cpu_baseline(wl, cfg, 0.0, min(n_frames + V_FRAMES, 6 + V_FRAMES), min_frames=6)
+    host = None
+    if full and not args.no_host_buffers and S.world == 1:
+        del d_depth
+        torch.cuda.empty_cache()
+        host = host_buffers_leg(wl, cfg, n_frames)
+
+    roof = rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct)
+    res = {
+        "workload": workload_string(config_name, cfg, wl),
+        "value": round(total_frames / t_max, 2), "ms_per_step": round(t_max / (steps * spg) * 1e3, 4), "steps": steps, "warmup": warmup,
+        "timed_s": round(t_max, 6),
+        "value_host_input": None if fps_host_input is None else round(fps_host_input, 2),
+        "phase_us": {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items() if v[1]},
+        "ate_m": ate, "data": wl.data,
+        "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks,
+        "roof": roof, "irate": irate, "prof": prof, "spg": spg,
+        "fps_total": None if fps_total is None else round(fps_total, 2), "fps_total_error": fps_total_error,
+        "fps_host_input_error": fps_host_input_error, "fps_host_buffers": host, "cpu_baseline": cpu,
+    }
+    return res
+
+
+def run(S, args, multi):
+    seen = multi.ranks_seen(S.dist, S.coll_device)
+    if seen != args.gpus:
+        raise SystemExit("bench.py: the all-reduce over the process group counted %d ranks, --gpus says %d" % (seen, args.gpus))
+    head = measure(S, args, multi, args.config, args.steps, args.warmup, True)
+    extra_names = args.extra_configs
+    if extra_names is None:
+        extra_names = "cfg3,cfg4" if (args.config == "cfg2" and args.streams_per_gpu == 1 and not args.host_input) else ""
+    extra = {}
+    for name in [n for n in extra_names.split(",") if n and n != "none"]:
+        if name not in CONFIGS:
+            raise SystemExit("bench.py: --extra-configs: unknown configuration %r" % name)
+        r = measure(S, args, multi, name, max(1, args.extra_steps), 8, False)
+        if r is not None:
+            extra[name] = r
+    if S.rank != 0:
+        return
+
+    def compact(r):      # what a leg under "configs" carries
+        if r.get("dry_run"):
+            return r
+        return {"workload": r["workload"], "value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                "warmup": r["warmup"], "timed_s": r["timed_s"], "value_host_input": r["value_host_input"], "value_host_input_error": r["fps_host_input_error"],
+                "n_gpus": S.world, "data": r["data"], "phase_us": r["phase_us"], "ate_m": r["ate_m"],
+                "icp_iterations_per_frame": r["icp_iterations_per_frame"], "roofline": r["roof"]}
+
+    W, H, vres = CONFIGS[args.config][:3]
+    if S.dry:
+        out = {"metric": "DRY RUN (--dry-collectives): rendezvous, barriers and all-reduces only, no frame was computed", "value": None,
+               "unit": "frames/s", "n_gpus": S.world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True,
+               "config": {"workload": args.config}, "timed_s": head["timed_s"], "frames_all_ranks": head["frames"],
+               "configs": {k: compact(v) for k, v in extra.items()}}
+        print(json.dumps(out))
+        return
+    roof, prof, irate = head["roof"], head["prof"], head["irate"]
     dominant = max(roof, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if roof else None
     out = {
         "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), %s, queued frames, "
                   "living-room stream %%dx%%d -c 1 @%%d^3" % ("PAGEABLE HOST INPUT (--host-input)" if args.host_input else "device-resident input") % (W, H, vres),
-        "value": round(total_frames / t_max, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(t_max / (args.steps * spg) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": wl.data,
-        "config": {"workload": "%s: %dx%d depth, -c 1 -v %d -y %s -r %d -z %d -s %g -p %s -k %s -m 0.1, one stream per GPU"
-                               % (args.config, W, H, vres, ",".join(map(str, pyramid)), irate, zrate, wl.volume_size,
-                                  ",".join("%g" % v for v in wl.init_factors), ",".join("%g" % v for v in wl.k)),
-                   "frames_per_gpu": args.steps * spg, "streams_per_gpu": spg, "icp_iterations_per_frame": round(icp_iters / n_frames, 2), "icp_solve_fallbacks": fallbacks},
-        "fps_total": None if fps_total is None else round(fps_total, 2),
-        "fps_queued_host_input": None if fps_host_input is None else round(fps_host_input, 2),
-        "fps_host_buffers": host,
-        "ate_m": ate,
-        "phase_us": {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items() if v[1]},
+        "value": head["value"], "unit": "frames/s", "n_gpus": S.world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "timed_s": head["timed_s"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": head["data"],
+        "config": {"workload": head["workload"],
+                   "frames_per_gpu": args.steps * head["spg"], "streams_per_gpu": head["spg"], "icp_iterations_per_frame": head["icp_iterations_per_frame"],
+                   "icp_solve_fallbacks": head["icp_solve_fallbacks"]},
+        # the same queued loop with every frame handed over as pageable host memory - what Kfusion::computeFrame(const ushort*) means
+        # (kernels.h:158-162); PCIe inside the loop, so by the bench contract it is reported beside `value`, never as it
+        "value_host_input": head["value_host_input"], "fps_queued_host_input": head["value_host_input"],
+        "fps_queued_host_input_error": head["fps_host_input_error"],
+        "fps_total": head["fps_total"], "fps_total_error": head["fps_total_error"],
+        "fps_host_buffers": head["fps_host_buffers"],
+        "ate_m": head["ate_m"],
+        "phase_us": head["phase_us"],
         "roofline": roof.get(dominant),
         "roofline_other": {k: v for k, v in roof.items() if k != dominant},
-        "cpu_baseline": cpu,
+        "cpu_baseline": head["cpu_baseline"],
+        "configs": {k: compact(v) for k, v in extra.items()},
     }
     print(json.dumps(out))
 

@@ -72,3 +72,13 @@ def all_ok(ok: bool, dist=None, device="cpu") -> bool:
     t = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.item() == 0.0
+
+
+def ranks_seen(dist=None, device="cpu") -> int:
+    """How many ranks the collective library really connected: an all-reduce (sum) of ones over the process group."""
+    if dist is None or not dist.is_initialized():
+        return 1
+    import torch
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(t.item()))
