@@ -26,7 +26,7 @@ inline void clean() { kfh_clean(); }
 
 class Kfusion {
     kfh_context *ctx_;
-    Matrix4 view_pose_storage_;
+    Matrix4 pose_;         // host copy of the camera pose, refreshed by every member that can change it (the reference's `pose`, kernels.h:87)
     Matrix4 *view_pose_;   // NULL = follow the camera (kernels.h:179-184)
     uint2 computation_size_;
     uint3 volume_resolution_;
@@ -51,6 +51,8 @@ class Kfusion {
         return r;
     }
     static void k4(const float4 &k, float out[4]) { out[0] = k.x; out[1] = k.y; out[2] = k.z; out[3] = k.w; }
+    // the pose lives on the device; tracking() / computeFrame() wait for their verdict anyway, so the copy costs no extra sync
+    void refresh_pose_() { kfh_get_pose(ctx_, &pose_.data[0].x); }
 
 public:
     // kernels.h:99-119
@@ -63,6 +65,7 @@ public:
         std::vector<int32_t> pyr(pyramid.begin(), pyramid.end());
         ctx_ = kfh_create(inputSize.x, inputSize.y, res, dim, pose, pyr.data(), (int32_t)pyr.size(), -1, 0);
         fail_if_null("Kfusion::Kfusion");
+        refresh_pose_();
     }
     // kernels.h:121-139
     Kfusion(uint2 inputSize, uint3 volumeResolution, float3 volumeDimensions, Matrix4 initPose, std::vector<int> &pyramid)
@@ -73,6 +76,7 @@ public:
         std::vector<int32_t> pyr(pyramid.begin(), pyramid.end());
         ctx_ = kfh_create_with_pose(inputSize.x, inputSize.y, res, dim, &initPose.data[0].x, pyr.data(), (int32_t)pyr.size(), -1, 0);
         fail_if_null("Kfusion::Kfusion");
+        refresh_pose_();
     }
     ~Kfusion() { kfh_destroy(ctx_); }
 
@@ -95,6 +99,7 @@ public:
         checked(r, "Kfusion::computeFrame");
         tracked_ = checked(kfh_get_tracked(ctx_), "Kfusion::computeFrame") != 0;
         integrated_ = checked(kfh_get_integrated(ctx_), "Kfusion::computeFrame") != 0;
+        refresh_pose_();
     }
 
     bool preprocessing(const ushort *inputDepth, const uint2 inputSize) {
@@ -106,6 +111,7 @@ public:
         float kk[4];
         k4(k, kk);
         tracked_ = checked(kfh_tracking(ctx_, kk, icp_threshold, tracking_rate, frame), "Kfusion::tracking") > 0;
+        refresh_pose_();   // (a rejected pose is rolled back by this call already - cpp:991 does it in integration() - so pose_ is final here)
         return tracked_;
     }
     bool raycasting(float4 k, float mu, uint frame) {
@@ -136,16 +142,13 @@ public:
     void renderDepth(uchar4 *out, uint2 outputSize) { kfh_render_depth(ctx_, &out->x, outputSize.x, outputSize.y); }
 
     Matrix4 getPose() {
-        Matrix4 m;
-        kfh_get_pose(ctx_, &m.data[0].x);
-        return m;
+        refresh_pose_();
+        return pose_;
     }
     void setViewPose(Matrix4 *value = NULL) { view_pose_ = value; }
-    Matrix4 *getViewPose() {
-        if (view_pose_) return view_pose_;
-        view_pose_storage_ = getPose();
-        return &view_pose_storage_;
-    }
+    // kernels.h:176-184: a pointer to the caller's matrix, or to the LIVE camera pose - a caller that keeps the pointer (the GUI
+    // mains do) sees the pose move: pose_ is rewritten in place by tracking() / computeFrame() / getPose()
+    Matrix4 *getViewPose() { return view_pose_ ? view_pose_ : &pose_; }
     float3 getModelDimensions() { return volume_dimensions_; }
     uint3 getModelResolution() { return volume_resolution_; }
     uint2 getComputationResolution() { return computation_size_; }

@@ -25,7 +25,9 @@ class Counters(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile the restatement (and oracle/_ref when /root/reference is present)."""
-    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))     # make decides what is stale
+    import sys
+    # make decides what is stale; its chatter goes to stderr (bench.py prints ONE line on stdout)
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), stdout=sys.stderr)
 
 
 _libs = {}
@@ -93,6 +95,7 @@ def lib(omp: bool = False):
         "orc_kfusion_set_counting": (None, [vp, i]),
         "orc_set_omp_reduce_mode": (None, [i]),
         "orc_set_omp_threads": (None, [i]),
+        "orc_set_reduce_emulation": (None, [i]),
         "orc_kfusion_buffer": (vp, [vp, C.c_char_p, C.POINTER(C.c_ulonglong)]),
     }
     for name_, (res, args) in sig.items():
@@ -112,6 +115,12 @@ def set_omp_reduce_mode(reference_style: bool) -> None:
     """-fopenmp build: True = the reduction is parallelised like the reference's OpenMP build (re-associated, SURVEY N8);
     False (default) = bit-identical to the serial build."""
     lib(True).orc_set_omp_reduce_mode(1 if reference_style else 0)
+
+
+def set_reduce_emulation(threads: int, omp: bool = True) -> None:
+    """> 0: reduce like the reference's OpenMP build (cpp:295-296) with that many threads under a FIXED schedule and combine
+    order (deterministic, whatever the host has); 0 = off.  Per library (serial / -fopenmp build)."""
+    lib(omp).orc_set_reduce_emulation(int(threads))
 
 
 def _p(a, t):

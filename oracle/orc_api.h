@@ -27,6 +27,7 @@ void orc_track(void *output, const float *inVertex, const float *inNormal, unsig
                const float *view16, float dist_threshold, float normal_threshold, int have_reference);
 void orc_reduce(float *out, const void *J, unsigned JW, unsigned JH, unsigned W, unsigned H);
 void orc_set_omp_threads(int n);                      /* -fopenmp build only */
+void orc_set_reduce_emulation(int threads);           /* either build: > 0 = the reference's OpenMP reduction (cpp:295-296) with that many threads, fixed combine order; 0 = off */
 void orc_set_omp_reduce_mode(int reference_style);   /* -fopenmp build only: 1 = re-associated like the reference's OpenMP build */
 int orc_update_pose(float *pose16, const float *output, float icp_threshold);
 int orc_check_pose(float *pose16, const float *oldPose16, const float *output, unsigned W, unsigned H, float track_threshold);

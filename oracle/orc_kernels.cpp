@@ -375,6 +375,52 @@ void orc_set_omp_threads(int n) {
 #endif
 }
 
+// Mode 2 (either build): the SAME re-association with a FIXED schedule - what `#pragma omp parallel for reduction(+:sums0..31)`
+// (cpp:295-296) computes with T threads under gcc's static schedule (iteration space of a row class cut into T contiguous
+// shares, the first n % T of them one longer; every share summed from 0.0f in row order) when the shares are combined in thread
+// order 0..T-1.  libgomp combines them in ARRIVAL order, which is the one thing that varies run to run; fixing it makes the
+// reference's own CPP-vs-OpenMP noise floor a reproducible number (tests/test_hip_fullsize.py, long-sequence parity).
+static int g_reduce_emulated_threads = 0;
+void orc_set_reduce_emulation(int threads) { g_reduce_emulated_threads = threads > 0 ? threads : 0; }
+
+static void reduce_rows_emulated_omp(float *out, const TrackRec *J, unsigned JW, unsigned W, unsigned H, int T) {
+    for (int b = 0; b < 8; ++b) {
+        const unsigned n = H > (unsigned)b ? (H - (unsigned)b + 7) / 8 : 0;      // iterations y = b, b + 8, ... < H
+        float s[32];
+        for (int i = 0; i < 32; ++i) s[i] = 0.0f;
+        const unsigned q = n / (unsigned)T, r = n % (unsigned)T;
+        unsigned first = 0;
+        for (int t = 0; t < T; ++t) {
+            const unsigned count = q + ((unsigned)t < r ? 1u : 0u);
+            float p[32];
+            for (int i = 0; i < 32; ++i) p[i] = 0.0f;
+            for (unsigned it = first; it < first + count; ++it) {
+                const unsigned y = (unsigned)b + 8 * it;
+                for (unsigned x = 0; x < W; ++x) {
+                    const TrackRec &row = J[x + y * JW];
+                    if (row.result < 1) {
+                        p[29] += row.result == -4 ? 1 : 0;
+                        p[30] += row.result == -5 ? 1 : 0;
+                        p[31] += row.result > -4 ? 1 : 0;
+                        continue;
+                    }
+                    p[0] += row.error * row.error;
+                    for (int i = 0; i < 6; ++i) p[1 + i] += row.error * row.J[i];
+                    int k = 7;
+                    for (int rr = 0; rr < 6; ++rr)
+                        for (int c = rr; c < 6; ++c) p[k++] += row.J[rr] * row.J[c];
+                    p[28] += 1;
+                }
+            }
+            first += count;
+            for (int i = 0; i < 32; ++i) s[i] += p[i];       // (a thread without iterations contributes its zeros, as in OpenMP)
+        }
+        for (int i = 0; i < 32; ++i) out[b * 32 + i] = s[i];
+    }
+    for (int j = 1; j < 8; ++j)
+        for (int i = 0; i < 32; ++i) out[i] += out[j * 32 + i];
+}
+
 #ifdef _OPENMP
 static void reduce_rows_reference_omp(float *out, const TrackRec *J, unsigned JW, unsigned W, unsigned H) {
     for (int b = 0; b < 8; ++b) {
@@ -407,6 +453,7 @@ static void reduce_rows_reference_omp(float *out, const TrackRec *J, unsigned JW
 void orc_reduce(float *out, const void *Jv, unsigned JW, unsigned JH, unsigned W, unsigned H) {
     (void)JH;
     const TrackRec *J = static_cast<const TrackRec *>(Jv);
+    if (g_reduce_emulated_threads > 0) { reduce_rows_emulated_omp(out, J, JW, W, H, g_reduce_emulated_threads); return; }
 #ifdef _OPENMP
     if (g_reduce_mode) { reduce_rows_reference_omp(out, J, JW, W, H); return; }
 #pragma omp parallel for schedule(static, 1)

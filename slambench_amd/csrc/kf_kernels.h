@@ -89,7 +89,6 @@ struct ControlArgs {
     M4 view_pose;
     unsigned log_capacity;
     float vol_dim[3];    // OP_INTEG_BEGIN: extent of the volume (integrate_bounds)
-    int clear_integrated;   // first of all: integrated = 0, integrate gate closed (the host skipped OP_INTEG_BEGIN, kfh_integration)
 };
 
 // Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_kernels.hip, "side jobs"):

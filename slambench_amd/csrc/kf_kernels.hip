@@ -682,7 +682,6 @@ __device__ __forceinline__ void track_begin(DevState *__restrict__ st, bool trac
 
 __device__ void control_ops(DevState *__restrict__ st, FrameLogEntry *__restrict__ log, int ops, const ControlArgs &a) {
     const bool track_frame = (a.frame % a.tracking_rate) == 0;   // cpp:927
-    if (a.clear_integrated) { st->integrated = 0; st->integ.enabled = 0; }
     if (ops & OP_TRACK_BEGIN) track_begin(st, track_frame, a.k);
     if (ops & OP_TRACK_END) {
         if (track_frame) {                                           // cpp:968-969

@@ -43,6 +43,11 @@ static bool hip_ok(hipError_t e, const char *what, const char *file, int line) {
 struct PendingCopy { void *dst; const void *src; size_t bytes; };
 
 struct kfh_context {
+    // Every C-ABI entry that takes a context holds this lock for its duration, and so does kfh_synchronise_all() for each context it
+    // visits: a thread that calls the argument-less synchroniseDevices() (every tock() of the driver) while another thread is inside
+    // a call on ITS context waits for that call instead of flushing the deferred frame / pending copies / event lists under its feet.
+    // Recursive: entries call each other (kfh_compute_frame -> kfh_preprocessing, ...).  Lock order: registry, then context.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -66,7 +71,6 @@ struct kfh_context {
     unsigned seen_barrier_timeouts = 0;
     unsigned seen_failed_frames = 0;
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
-    bool clear_integrated = false;     // kfh_integration decided "not integrated" on the host: the device flag follows with the next control operation
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
@@ -188,11 +192,19 @@ static void fill_control(kfh_context *c, ControlArgs &a, const float k[4], unsig
     a.view_pose = c->viewPose;
     a.log_capacity = c->log_capacity;
     a.vol_dim[0] = c->volDim.x; a.vol_dim[1] = c->volDim.y; a.vol_dim[2] = c->volDim.z;
-    a.clear_integrated = c->clear_integrated ? 1 : 0;
-    c->clear_integrated = false;       // (every caller launches the operation it fills in)
 }
 
 // a kernel launch the runtime rejected since the last check: named in kfh_last_error(), sticky in the context
+static bool launches_ok(kfh_context *c);
+// RAII of a C-ABI entry: the context's lock, and on the way out any launch the runtime rejected during the call is booked to THIS
+// context (the launch error is per thread; an entry that returned without looking would leave it to whichever context asks next)
+struct Entry {
+    kfh_context *c;
+    explicit Entry(kfh_context *ctx) : c(ctx) { if (c) c->mu.lock(); }
+    ~Entry() { launches_ok(c); if (c) c->mu.unlock(); }
+    Entry(const Entry &) = delete;
+    Entry &operator=(const Entry &) = delete;
+};
 static bool launches_ok(kfh_context *c) {
     if (const char *e = launch::take_launch_error()) {
         g_last_error = e;
@@ -796,15 +808,14 @@ void kfh_destroy(kfh_context *c) {
     delete c;
 }
 
-void kfh_reset(kfh_context *c) {
+void kfh_reset(kfh_context *c) { Entry e_(c);
     flush_frame(c);
     if (c->error == KFH_ERR_BARRIER) c->error = KFH_OK;   // a new sequence on a fresh volume: the failed frame is history
-    c->clear_integrated = false;
     launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     HIP_TRY(hipMemsetAsync(c->d_skip, 0, launch::skip_grid_bytes(c->volRes[0], c->volRes[1], c->volRes[2]), c->stream));
 }
 
-void kfh_synchronise(kfh_context *c) {
+void kfh_synchronise(kfh_context *c) { Entry e_(c);
     flush_frame(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->kernel_timings) prof_collect(c);
@@ -821,12 +832,12 @@ void kfh_synchronise_all(void) {
     hipGetDevice(&before);
     for (kfh_context *c : g_registry) {
         hipSetDevice(c->device);
-        kfh_synchronise(c);
+        kfh_synchronise(c);      // (takes the context's lock: a call another thread is making on c finishes first)
     }
     hipSetDevice(before);
 }
 
-int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) {
+int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in_width, uint32_t in_height) { Entry e_(c);
     if (!c || !host_depth_mm) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     c->queued_api = false;
@@ -840,7 +851,7 @@ int kfh_preprocessing(kfh_context *c, const uint16_t *host_depth_mm, uint32_t in
     return launches_ok(c) ? r : KFH_ERR_HIP;
 }
 
-int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height) {
+int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, uint32_t in_width, uint32_t in_height) { Entry e_(c);
     if (!c || !device_depth_mm) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     c->queued_api = false;
@@ -849,7 +860,7 @@ int kfh_preprocessing_device(kfh_context *c, const uint16_t *device_depth_mm, ui
     return r;
 }
 
-int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame) {
+int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame) { Entry e_(c);
     if (!c || !k || !tracking_rate) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     enqueue_tracking(c, k, icp_threshold, tracking_rate, frame, OP_TRACK_END, 1);
@@ -860,20 +871,20 @@ int kfh_tracking(kfh_context *c, const float k[4], float icp_threshold, uint32_t
     return c->h_state->tracked;
 }
 
-int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate, float mu, uint32_t frame) {
+int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate, float mu, uint32_t frame) { Entry e_(c);
     if (!c || !k || !integration_rate) return KFH_ERR_ARGUMENT;
     flush_frame(c);
-    if ((frame % integration_rate) != 0 && frame > 3) {
-        // cpp:994: off the integration rate and past frame 3 the frame is not integrated whatever tracking said, and the pose
-        // roll-back of a bad track (cpp:991) has been applied by tracking() already: nothing to launch, nothing to wait for.
-        // The device flags follow with the next control operation (raycasting's), the host's view at once.
-        c->clear_integrated = true;
-        c->h_state->integrated = 0;
-        return c->error ? c->error : 0;
-    }
     ControlArgs a;
     fill_control(c, a, k, frame, 1, integration_rate);
     launch::control(c->d_state, c->d_log, OP_INTEG_BEGIN, a, c->stream);
+    if ((frame % integration_rate) != 0 && frame > 3) {
+        // cpp:994: off the integration rate and past frame 3 the frame is not integrated whatever checkPose says, so the verdict
+        // is known on the host: k_integrate is not launched and nothing is waited for.  The control operation above still
+        // runs the reference's checkPose step and gate on the device (cpp:991-994), so DevState (integrated, integ.enabled,
+        // the rolled-back pose) is what the reference's members would hold for every later reader of the device state.
+        c->mirror_stale = true;
+        return c->error ? c->error : 0;
+    }
     enqueue_integrate(c, mu);
     c->mirror_stale = true;
     launches_ok(c);
@@ -882,7 +893,7 @@ int kfh_integration(kfh_context *c, const float k[4], uint32_t integration_rate,
     return c->h_state->integrated;
 }
 
-int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
+int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) { Entry e_(c);
     if (!c || !k) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     ControlArgs a;
@@ -896,7 +907,7 @@ int kfh_raycasting(kfh_context *c, const float k[4], float mu, uint32_t frame) {
 
 int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is_device, uint32_t in_width,
                       uint32_t in_height, const float k[4], uint32_t integration_rate, uint32_t tracking_rate,
-                      float icp_threshold, float mu, uint32_t frame) {
+                      float icp_threshold, float mu, uint32_t frame) { Entry e_(c);
     if (!c || !depth_mm || !k || !integration_rate || !tracking_rate) return KFH_ERR_ARGUMENT;
     const bool was_queued = true;
     if (!c->pipelined) {
@@ -961,7 +972,7 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
     c->pending.push_back(p);
 }
 
-void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
+void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
     if (!c || !out || w != c->W || h != c->H) return;
     flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_DEPTH);
@@ -970,7 +981,7 @@ void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     queue_readback(c, 0, out, w, h);
 }
 
-void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
+void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
     if (!c || !out || w != c->W || h != c->H) return;
     flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_TRACK);
@@ -980,7 +991,7 @@ void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
 }
 
 void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, int32_t rate, const float k[4],
-                       float largestep) {
+                       float largestep) { Entry e_(c);
     if (!c || !out || !k || w != c->W || h != c->H || rate == 0) return;
     flush_frame(c);
     if (frame % rate != 0) return;   // cpp:1034
@@ -996,7 +1007,7 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
     queue_readback(c, 2, out, w, h);
 }
 
-int kfh_dump_volume(kfh_context *c, const char *filename) {
+int kfh_dump_volume(kfh_context *c, const char *filename) { Entry e_(c);
     if (!c) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     if (!filename) return KFH_OK;   // cpp:1010-1012
@@ -1014,41 +1025,41 @@ int kfh_dump_volume(kfh_context *c, const char *filename) {
     return wr == n ? KFH_OK : KFH_ERR_IO;
 }
 
-void kfh_get_pose(kfh_context *c, float out16[16]) { refresh_mirror(c); std::memcpy(out16, &c->h_state->pose, sizeof(M4)); }
+void kfh_get_pose(kfh_context *c, float out16[16]) { Entry e_(c); refresh_mirror(c); std::memcpy(out16, &c->h_state->pose, sizeof(M4)); }
 
-void kfh_set_pose(kfh_context *c, const float in16[16]) {
+void kfh_set_pose(kfh_context *c, const float in16[16]) { Entry e_(c);
     refresh_mirror(c);
     std::memcpy(&c->h_state->pose, in16, sizeof(M4));
     HIP_TRY(hipMemcpyAsync(&c->d_state->pose, &c->h_state->pose, sizeof(M4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 }
 
-void kfh_get_position(kfh_context *c, float out3[3]) {   // kernels.h:147-154
+void kfh_get_position(kfh_context *c, float out3[3]) { Entry e_(c);   // kernels.h:147-154
     refresh_mirror(c);
     for (int i = 0; i < 3; ++i) out3[i] = c->h_state->pose.m[i][3] - c->initPose[i];
 }
-int kfh_get_tracked(kfh_context *c) { refresh_mirror(c); return c->error ? c->error : c->h_state->tracked; }
-int kfh_get_integrated(kfh_context *c) {
+int kfh_get_tracked(kfh_context *c) { Entry e_(c); refresh_mirror(c); return c->error ? c->error : c->h_state->tracked; }
+int kfh_get_integrated(kfh_context *c) { Entry e_(c);
     refresh_mirror(c);
     if (c->error) return c->error;
-    return c->clear_integrated ? 0 : c->h_state->integrated;
+    return c->h_state->integrated;
 }
-int kfh_get_error(kfh_context *c) {
+int kfh_get_error(kfh_context *c) { Entry e_(c);
     if (!c) return KFH_ERR_ARGUMENT;
     launches_ok(c);
     c->mirror_stale = true;
     refresh_mirror(c);
     return c->error;
 }
-void kfh_set_view_pose(kfh_context *c, const float *vp) {   // kernels.h:179-184
+void kfh_set_view_pose(kfh_context *c, const float *vp) { Entry e_(c);   // kernels.h:179-184
     if (vp) { std::memcpy(&c->viewPose, vp, sizeof(M4)); c->useViewPose = true; }
     else c->useViewPose = false;
 }
-void kfh_get_model_dimensions(kfh_context *c, float o[3]) { o[0] = c->volDim.x; o[1] = c->volDim.y; o[2] = c->volDim.z; }
-void kfh_get_model_resolution(kfh_context *c, uint32_t o[3]) { for (int i = 0; i < 3; ++i) o[i] = c->volRes[i]; }
-void kfh_get_computation_resolution(kfh_context *c, uint32_t o[2]) { o[0] = c->W; o[1] = c->H; }
+void kfh_get_model_dimensions(kfh_context *c, float o[3]) { Entry e_(c); o[0] = c->volDim.x; o[1] = c->volDim.y; o[2] = c->volDim.z; }
+void kfh_get_model_resolution(kfh_context *c, uint32_t o[3]) { Entry e_(c); for (int i = 0; i < 3; ++i) o[i] = c->volRes[i]; }
+void kfh_get_computation_resolution(kfh_context *c, uint32_t o[2]) { Entry e_(c); o[0] = c->W; o[1] = c->H; }
 
-int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracked, int32_t *integrated) {
+int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracked, int32_t *integrated) { Entry e_(c);
     if (!c || n > c->log_capacity) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     std::vector<FrameLogEntry> host(n);
@@ -1064,28 +1075,28 @@ int kfh_read_frame_log(kfh_context *c, uint32_t n, float *poses, int32_t *tracke
     return KFH_OK;
 }
 
-uint64_t kfh_solve_fallbacks(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->solve_fallbacks; }
-uint64_t kfh_barrier_timeouts(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->barrier_timeouts; }
-uint64_t kfh_integrate_updated(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
+uint64_t kfh_solve_fallbacks(kfh_context *c) { Entry e_(c); c->mirror_stale = true; refresh_mirror(c); return c->h_state->solve_fallbacks; }
+uint64_t kfh_barrier_timeouts(kfh_context *c) { Entry e_(c); c->mirror_stale = true; refresh_mirror(c); return c->h_state->barrier_timeouts; }
+uint64_t kfh_integrate_updated(kfh_context *c) { Entry e_(c); c->mirror_stale = true; refresh_mirror(c); return c->h_state->integrate_updated; }
 
-void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) {
+void kfh_set_profiling(kfh_context *c, uint32_t phase_mask) { Entry e_(c);
     flush_frame(c);
     prof_collect(c);
     c->prof_mask = c->kernel_timings ? ((1u << KFH_PROF_COUNT) - 1u) : phase_mask;
     for (int p = 0; p < KFH_PROF_COUNT; ++p) { c->prof_ms[p] = 0; c->prof_n[p] = 0; c->prof_issued[p] = 0; }
 }
 
-void kfh_set_profiling_stride(kfh_context *c, uint32_t every_n_frames) {
+void kfh_set_profiling_stride(kfh_context *c, uint32_t every_n_frames) { Entry e_(c);
     if (!c) return;
     c->prof_stride = every_n_frames ? every_n_frames : 1;
     c->prof_tick = 0;
 }
 
-void kfh_set_profiling_rotation(kfh_context *c, int32_t one_phase_per_sampled_frame) {
+void kfh_set_profiling_rotation(kfh_context *c, int32_t one_phase_per_sampled_frame) { Entry e_(c);
     if (c) c->prof_rotate = one_phase_per_sampled_frame != 0;
 }
 
-int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]) {
+int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t launches_out[KFH_PROF_COUNT]) { Entry e_(c);
     if (!c) return KFH_ERR_ARGUMENT;
     flush_frame(c);
     prof_collect(c);
@@ -1093,8 +1104,8 @@ int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t lau
     return KFH_OK;
 }
 
-uint64_t kfh_icp_iterations(kfh_context *c) { c->mirror_stale = true; refresh_mirror(c); return c->h_state->icp_iterations; }
-void kfh_icp_level_iterations(kfh_context *c, uint64_t out[KFH_MAX_LEVELS]) {
+uint64_t kfh_icp_iterations(kfh_context *c) { Entry e_(c); c->mirror_stale = true; refresh_mirror(c); return c->h_state->icp_iterations; }
+void kfh_icp_level_iterations(kfh_context *c, uint64_t out[KFH_MAX_LEVELS]) { Entry e_(c);
     c->mirror_stale = true;
     refresh_mirror(c);
     for (int l = 0; l < KFH_MAX_LEVELS; ++l) out[l] = c->h_state->icp_level_iterations[l];
@@ -1124,7 +1135,7 @@ static bool find_buffer(kfh_context *c, const std::string &n, void **ptr, size_t
     return false;
 }
 
-int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64_t capacity) {
+int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64_t capacity) { Entry e_(c);
     void *p; size_t b;
     flush_frame(c);
     if (!c || !name || !find_buffer(c, name, &p, &b)) return KFH_ERR_ARGUMENT;
@@ -1135,7 +1146,7 @@ int64_t kfh_read_buffer(kfh_context *c, const char *name, void *host_out, uint64
     return (int64_t)b;
 }
 
-int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, uint64_t nbytes) {
+int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, uint64_t nbytes) { Entry e_(c);
     void *p; size_t b;
     flush_frame(c);
     if (!c || !name || !host_in || !find_buffer(c, name, &p, &b) || nbytes != b) return KFH_ERR_ARGUMENT;
@@ -1147,7 +1158,7 @@ int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, 
     return (int64_t)b;
 }
 
-void *kfh_device_pointer(kfh_context *c, const char *name) {
+void *kfh_device_pointer(kfh_context *c, const char *name) { Entry e_(c);
     void *p; size_t b;
     flush_frame(c);
     if (!c || !name || !find_buffer(c, name, &p, &b)) return nullptr;
@@ -1181,7 +1192,7 @@ static void *scratch(size_t bytes, hipStream_t s) {
 static M4 load16(const float *p) { M4 m; std::memcpy(&m, p, sizeof m); return m; }
 static Gauss5 load_gauss(const float *g5) { Gauss5 g; for (int i = 0; i < 5; ++i) g.g[i] = g5[i]; return g; }
 
-void kfh_k_init_volume(int16_t *vol, const uint32_t size[3], void *stream) {
+void kfh_k_init_volume(int16_t *vol, const uint32_t size[3], void *stream) { Entry e_(nullptr);
     launch::init_volume(vol, size[0], size[1], size[2], (hipStream_t)stream);
 }
 
@@ -1193,21 +1204,21 @@ static int ratio_of(uint32_t out_w, uint32_t out_h, uint32_t in_w, uint32_t in_h
     return (int)(in_w / out_w);
 }
 
-int kfh_k_mm2meters(float *out, uint32_t out_w, uint32_t out_h, const uint16_t *in, uint32_t in_w, uint32_t in_h, void *stream) {
+int kfh_k_mm2meters(float *out, uint32_t out_w, uint32_t out_h, const uint16_t *in, uint32_t in_w, uint32_t in_h, void *stream) { Entry e_(nullptr);
     const int r = ratio_of(out_w, out_h, in_w, in_h);
     if (r < 0) return KFH_ERR_INVALID_RATIO;
     launch::mm2meters(out, out_w, out_h, in, in_w, r, (hipStream_t)stream);
     return KFH_OK;
 }
 
-void kfh_k_bilateral_filter(float *out, const float *in, uint32_t w, uint32_t h, const float *g5, float e_d, int32_t r, void *stream) {
+void kfh_k_bilateral_filter(float *out, const float *in, uint32_t w, uint32_t h, const float *g5, float e_d, int32_t r, void *stream) { Entry e_(nullptr);
     if (r != radius) { g_last_error = "bilateral radius must be 2"; return; }
     launch::prepare_bilateral_division(e_d, (hipStream_t)stream);
     launch::bilateral(out, in, w, h, load_gauss(g5), e_d, (hipStream_t)stream);
 }
 
 int kfh_k_preprocess(float *float_depth, float *filtered, uint32_t w, uint32_t h, const uint16_t *in, uint32_t in_w, uint32_t in_h,
-                     const float *g5, float e_d, void *stream) {
+                     const float *g5, float e_d, void *stream) { Entry e_(nullptr);
     const int r = ratio_of(w, h, in_w, in_h);
     if (r < 0) return KFH_ERR_INVALID_RATIO;
     launch::prepare_bilateral_division(e_d, (hipStream_t)stream);
@@ -1215,20 +1226,20 @@ int kfh_k_preprocess(float *float_depth, float *filtered, uint32_t w, uint32_t h
     return KFH_OK;
 }
 
-void kfh_k_half_sample(float *out, const float *in, uint32_t in_w, uint32_t in_h, float e_d, int32_t r, void *stream) {
+void kfh_k_half_sample(float *out, const float *in, uint32_t in_w, uint32_t in_h, float e_d, int32_t r, void *stream) { Entry e_(nullptr);
     if (r != 1) { g_last_error = "half sample radius must be 1"; return; }
     launch::half_sample(out, in, in_w, in_h, e_d, (hipStream_t)stream);
 }
 
-void kfh_k_depth2vertex(float *vertex4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) {
+void kfh_k_depth2vertex(float *vertex4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) { Entry e_(nullptr);
     launch::depth2vertex(reinterpret_cast<float4 *>(vertex4), depth, w, h, load16(invK16), (hipStream_t)stream);
 }
 
-void kfh_k_vertex2normal(float *normal4, const float *vertex4, uint32_t w, uint32_t h, void *stream) {
+void kfh_k_vertex2normal(float *normal4, const float *vertex4, uint32_t w, uint32_t h, void *stream) { Entry e_(nullptr);
     launch::vertex2normal(reinterpret_cast<float4 *>(normal4), reinterpret_cast<const float4 *>(vertex4), w, h, (hipStream_t)stream);
 }
 
-void kfh_k_vertex_normal(float *vertex4, float *normal4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) {
+void kfh_k_vertex_normal(float *vertex4, float *normal4, const float *depth, uint32_t w, uint32_t h, const float invK16[16], void *stream) { Entry e_(nullptr);
     launch::vertex_normal(reinterpret_cast<float4 *>(vertex4), reinterpret_cast<float4 *>(normal4), depth, w, h, load16(invK16), (hipStream_t)stream);
 }
 
@@ -1256,7 +1267,7 @@ static void track_common(float *out32, int32_t *result_map, kfh_track_data *trac
 
 void kfh_k_track(kfh_track_data *output, const float *in_vertex4, const float *in_normal4, uint32_t in_w, uint32_t in_h,
                  const float *ref_vertex4, const float *ref_normal4, uint32_t ref_w, uint32_t ref_h, const float T16[16],
-                 const float view16[16], float dist_thr, float normal_thr, int32_t have_reference, void *stream) {
+                 const float view16[16], float dist_thr, float normal_thr, int32_t have_reference, void *stream) { Entry e_(nullptr);
     track_common(nullptr, nullptr, output, in_vertex4, in_normal4, in_w, in_h, ref_vertex4, ref_normal4, ref_w, ref_h, T16,
                  view16, dist_thr, normal_thr, have_reference, (hipStream_t)stream);
 }
@@ -1264,12 +1275,12 @@ void kfh_k_track(kfh_track_data *output, const float *in_vertex4, const float *i
 void kfh_k_track_reduce(float *out32, int32_t *result_map, const float *in_vertex4, const float *in_normal4, uint32_t in_w,
                         uint32_t in_h, const float *ref_vertex4, const float *ref_normal4, uint32_t ref_w, uint32_t ref_h,
                         const float T16[16], const float view16[16], float dist_thr, float normal_thr, int32_t have_reference,
-                        void *stream) {
+                        void *stream) { Entry e_(nullptr);
     track_common(out32, result_map, nullptr, in_vertex4, in_normal4, in_w, in_h, ref_vertex4, ref_normal4, ref_w, ref_h, T16,
                  view16, dist_thr, normal_thr, have_reference, (hipStream_t)stream);
 }
 
-void kfh_k_reduce(float *out8x32, const kfh_track_data *J, uint32_t j_w, uint32_t j_h, uint32_t w, uint32_t h, void *stream) {
+void kfh_k_reduce(float *out8x32, const kfh_track_data *J, uint32_t j_w, uint32_t j_h, uint32_t w, uint32_t h, void *stream) { Entry e_(nullptr);
     (void)j_h;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
@@ -1282,7 +1293,7 @@ void kfh_k_reduce(float *out8x32, const kfh_track_data *J, uint32_t j_w, uint32_
     HIP_TRY(hipStreamSynchronize(s));
 }
 
-int kfh_k_update_pose(float *pose16, const float *reduction32, float icp_threshold, void *stream) {
+int kfh_k_update_pose(float *pose16, const float *reduction32, float icp_threshold, void *stream) { Entry e_(nullptr);
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     int *flag = static_cast<int *>(scratch(sizeof(int), s));
@@ -1294,7 +1305,7 @@ int kfh_k_update_pose(float *pose16, const float *reduction32, float icp_thresho
     return h;
 }
 
-int kfh_k_check_pose(float *pose16, const float *old_pose16, const float *reduction32, uint32_t w, uint32_t h, float thr, void *stream) {
+int kfh_k_check_pose(float *pose16, const float *old_pose16, const float *reduction32, uint32_t w, uint32_t h, float thr, void *stream) { Entry e_(nullptr);
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     int *flag = static_cast<int *>(scratch(sizeof(int), s));
@@ -1307,7 +1318,7 @@ int kfh_k_check_pose(float *pose16, const float *old_pose16, const float *reduct
 }
 
 void kfh_k_integrate(int16_t *vol, const uint32_t size[3], const float dim[3], const float *depth, uint32_t w, uint32_t h,
-                     const float inv_track16[16], const float K16[16], float mu, float maxw, void *stream) {
+                     const float inv_track16[16], const float K16[16], float mu, float maxw, void *stream) { Entry e_(nullptr);
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     IntegrateParams *d = static_cast<IntegrateParams *>(scratch(sizeof(IntegrateParams), s));
@@ -1334,7 +1345,7 @@ static RayParams *upload_ray(const float view16[16], hipStream_t s) {
 
 void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const int16_t *vol, const uint32_t size[3],
                    const float dim[3], const float view16[16], float near_plane, float far_plane, float step, float largestep,
-                   void *stream) {
+                   void *stream) { Entry e_(nullptr);
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     RayParams *d = upload_ray(view16, s);
@@ -1344,17 +1355,17 @@ void kfh_k_raycast(float *vertex4, float *normal4, uint32_t w, uint32_t h, const
     HIP_TRY(hipStreamSynchronize(s));
 }
 
-void kfh_k_render_depth(uint8_t *out, const float *depth, uint32_t w, uint32_t h, float near_plane, float far_plane, void *stream) {
+void kfh_k_render_depth(uint8_t *out, const float *depth, uint32_t w, uint32_t h, float near_plane, float far_plane, void *stream) { Entry e_(nullptr);
     launch::render_depth(reinterpret_cast<uchar4 *>(out), depth, w, h, near_plane, far_plane, (hipStream_t)stream);
 }
 
-void kfh_k_render_track(uint8_t *out, const int32_t *result_map, uint32_t w, uint32_t h, void *stream) {
+void kfh_k_render_track(uint8_t *out, const int32_t *result_map, uint32_t w, uint32_t h, void *stream) { Entry e_(nullptr);
     launch::render_track(reinterpret_cast<uchar4 *>(out), result_map, w, h, (hipStream_t)stream);
 }
 
 void kfh_k_render_volume(uint8_t *out, uint32_t w, uint32_t h, const int16_t *vol, const uint32_t size[3], const float dim[3],
                          const float view16[16], float near_plane, float far_plane, float step, float largestep,
-                         const float light[3], const float ambient[3], void *stream) {
+                         const float light[3], const float ambient[3], void *stream) { Entry e_(nullptr);
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_scratch.mu);
     RayParams *d = upload_ray(view16, s);

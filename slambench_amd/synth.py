@@ -168,3 +168,36 @@ def cached_stream(n_frames: int, width: int = 640, height: int = 480, seed: int 
     np.savez(tmp, depth=s.depth_mm, poses=s.poses)
     os.replace(tmp, path)
     return s
+
+
+def write_scene_dir(directory: str, stream: Stream, seed: int = 4321) -> None:
+    """The stream as an ICL-NUIM scene directory (what `SceneDepthReader`, interface.h:99-197, and `scene2raw` read): per frame
+    ``scene_00_%04d.depth`` = 640x480 RAY LENGTHS in metres as text - the z-depth of the stream divided back through the ICL-NUIM
+    conversion ``z = ray / sqrt(((u - 319.5) / 481.2)^2 + ((v - 239.5) / -480)^2 + 1)`` (interface.h:181-193) - and a grey
+    ``scene_00_%04d.png`` (KinectFusion never reads the colours).  The stream's integer millimetres get a seeded fractional part
+    first: ICL-NUIM's ray lengths are not quantised, and whole millimetres would put every pixel on the truncation boundary of
+    the readers' float -> ushort conversion."""
+    import zlib
+    if (stream.width, stream.height) != (640, 480):
+        raise ValueError("ICL-NUIM scene files are 640x480")
+    os.makedirs(directory, exist_ok=True)
+    u, v = np.meshgrid(np.arange(640, dtype=np.float64), np.arange(480, dtype=np.float64))
+    scale = np.sqrt(((u - 319.5) / 481.2) ** 2 + ((v - 239.5) / -480.0) ** 2 + 1.0)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    rng = np.random.default_rng(seed)
+    for i in range(stream.depth_mm.shape[0]):
+        mm = stream.depth_mm[i].astype(np.float64)
+        mm = np.where(mm > 0, mm + rng.uniform(0.0, 1.0, size=mm.shape), 0.0)
+        rays = mm / 1000.0 * scale
+        with open(os.path.join(directory, "scene_00_%04d.depth" % i), "w") as f:
+            f.write(" ".join("%.6f" % x for x in rays.reshape(-1)))
+            f.write(" ")
+        g = np.clip(stream.depth_mm[i].astype(np.float64) / 4000.0 * 255.0, 0, 255).astype(np.uint8)
+        rgb = np.repeat(g[..., None], 3, axis=-1)
+        raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(480))
+        with open(os.path.join(directory, "scene_00_%04d.png" % i), "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 640, 480, 8, 2, 0, 0, 0))
+                    + chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))

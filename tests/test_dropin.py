@@ -155,3 +155,59 @@ def test_device_side_failure_is_fatal_in_the_cpp_class(tmp_path):
     assert r.returncode == 1
     assert "preprocessed" in r.stdout and "NOT REACHED" not in r.stdout
     assert "Kfusion::tracking failed (-5): stub: ICP grid barrier timed out" in r.stderr
+
+
+VIEWPOSE_DRIVER = r"""
+#include <kernels.h>
+#include <interface.h>
+#include <cstring>
+// kernels.h:176-184 of the reference: getViewPose() hands out a pointer to the LIVE camera pose (viewPose = &pose) unless the caller
+// set a matrix of its own.  A GUI-style caller takes the pointer once and reads through it every frame.
+int main(int argc, char **argv) {
+    DepthReader *reader = new RawDepthReader(argv[1], 0, false);
+    const uint2 size = reader->getinputSize();
+    std::vector<int> pyramid; pyramid.push_back(10); pyramid.push_back(5); pyramid.push_back(4);
+    Kfusion kfusion(size, make_uint3(64, 64, 64), make_float3(4.8f, 4.8f, 4.8f), make_float3(1.632f, 2.4f, 1.152f), pyramid);
+    Matrix4 *held = kfusion.getViewPose();                       // taken ONCE, before any frame
+    std::vector<uint16_t> depth(size.x * size.y);
+    float4 k = make_float4(120.3f, 120.f, 80.f, 60.f);
+    int moved = 0;
+    Matrix4 first = *held;
+    for (uint frame = 0; reader->readNextDepthFrame(depth.data()); ++frame) {
+        kfusion.preprocessing(depth.data(), size);
+        kfusion.tracking(k, 1e-5f, 1, frame);
+        kfusion.integration(k, 1, 0.1f, frame);
+        kfusion.raycasting(k, 0.1f, frame);
+        const Matrix4 now = kfusion.getPose();
+        if (kfusion.getViewPose() != held) { std::printf("pointer changed\n"); return 2; }
+        if (std::memcmp(held, &now, sizeof now) != 0) { std::printf("stale at frame %u\n", frame); return 3; }
+        if (std::memcmp(&first, &now, sizeof now) != 0) moved = 1;
+    }
+    Matrix4 mine = first;
+    kfusion.setViewPose(&mine);
+    if (kfusion.getViewPose() != &mine) return 4;
+    kfusion.setViewPose();
+    if (kfusion.getViewPose() != held) return 5;
+    std::printf("ok moved=%d\n", moved);
+    return 0;
+}
+"""
+
+
+def test_get_view_pose_follows_the_live_pose(tmp_path):
+    """the pointer getViewPose() returns must follow the pose like the reference's `&pose`.  Run over the CPU
+    restatement behind the same C ABI (oracle/orc_kfh_shim.cpp): the class logic under test is host-only."""
+    from slambench_amd import synth
+    s = synth.make_stream(10, 160, 120)
+    raw = tmp_path / "s.raw"
+    synth.write_raw(str(raw), s)
+    (tmp_path / "driver.cpp").write_text(VIEWPOSE_DRIVER)
+    orc_dir = os.path.join(ROOT, "oracle")
+    cmd = ["g++", "-O2", "-std=gnu++11", "-ffp-contract=off", "-w", "-I", os.path.join(ROOT, "include", "kfusion"), "-I", os.path.join(ROOT, "include"),
+           str(tmp_path / "driver.cpp"), os.path.join(orc_dir, "orc_kfh_shim.cpp"), os.path.join(orc_dir, "orc_kernels.cpp"),
+           os.path.join(orc_dir, "orc_pipeline.cpp"), "-o", str(tmp_path / "driver"), "-lm", "-lrt", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(tmp_path / "driver"), str(raw)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok moved=1" in r.stdout          # the pose did change over the run, and the held pointer saw every change

@@ -1,0 +1,207 @@
+"""Round-3 parity cases: BASELINE configs[2] as a pipeline, a long free-running sequence against a noise floor with a
+FIXED thread schedule, the queued host-input path in the driver's shape, and two threads driving their own contexts while the
+argument-less synchroniseDevices() (kfh_synchronise_all) runs."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.util import same_bits
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480
+
+
+@pytest.fixture(scope="module")
+def kfmod(hip):
+    from slambench_amd import kfusion
+    return kfusion
+
+
+def test_config2_512_r1_z1_pipeline_against_oracle(hip, kfmod, orc):
+    """BASELINE configs[2] with its own flag set: 640x480, `-v 512,512,512 -r 1 -z 1` (integrate on every frame, renderVolume on
+    every frame; cpp:988-1004, 1032-1046).  Lock-step with the OpenMP oracle over 6 frames - the GPU pose is overwritten with the
+    oracle's before tracking and before integration, so every stage sees identical inputs: TSDF, raycast vertex / normal maps and
+    the three render images bit-identical on every frame, verdicts equal; then the queued path (kfh_compute_frame + the three
+    renders per frame, as bench.py's fps_total leg issues them) against free-running phase calls, bit for bit."""
+    n = 6
+    s = util.synth.make_stream(n, W, H)
+    k = list(s.k)
+    res, irate, zrate = (512, 512, 512), 1, 1
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+    f_run = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    q = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    q_img = [np.zeros((H, W, 4), np.uint8) for _ in range(3)]
+    u8 = C.POINTER(C.c_uint8)
+    for f in range(n):
+        g.set_pose(o.get_pose())
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        tg, to = g.tracking(k, util.ICP_THRESHOLD, 1, f), o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        assert tg == to, f
+        assert np.abs(g.get_pose() - o.get_pose()).max() <= 2e-5, f
+        g.set_pose(o.get_pose())
+        ig, io = g.integration(k, irate, util.MU, f), o.integration(k, irate, util.MU, f)
+        assert ig == io == True, f                                      # noqa: E712  (-r 1: every frame of this stream integrates)
+        assert np.array_equal(g.buffer("volume"), o.buffer("volume")), "TSDF differs at frame %d" % f
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        assert same_bits(g.buffer("vertex")[..., :3], o.buffer("vertex")), f
+        assert same_bits(g.buffer("normal")[..., :3], o.buffer("normal")), f
+        assert np.array_equal(g.render_depth(), o.render_depth()), f
+        # (renderTrack shows the result map of the last ICP iteration: exact whenever both ran the same iterations on the same pose)
+        assert np.array_equal(g.render_track(), o.render_track()) or f >= 4, f
+        vg, vo = g.render_volume(f, zrate, k, 0.75 * util.MU), o.render_volume(f, zrate, k, 0.75 * util.MU)
+        assert np.array_equal(vg, vo), f
+        assert f < 3 or (vo[..., :3].max() > 0 and (o.buffer("normal")[..., 0] != -2).mean() > 0.5)     # a real surface is rendered
+        # free-running phases against the queued path with renders, same library
+        f_run.preprocessing(s.depth_mm[f]); f_run.tracking(k, util.ICP_THRESHOLD, 1, f); f_run.integration(k, irate, util.MU, f); f_run.raycasting(k, util.MU, f)
+        q.compute_frame(s.depth_mm[f], (W, H), k, irate, 1, util.ICP_THRESHOLD, util.MU, f)
+        q.L.kfh_render_depth(q.h, q_img[0].ctypes.data_as(u8), W, H)
+        q.L.kfh_render_track(q.h, q_img[1].ctypes.data_as(u8), W, H)
+        q.L.kfh_render_volume(q.h, q_img[2].ctypes.data_as(u8), W, H, f, zrate, (C.c_float * 4)(*k), 0.75 * util.MU)
+    q.synchronise()
+    for name in ("volume", "vertex", "normal", "trackResult", "floatDepth", "pose"):
+        assert np.array_equal(f_run.buffer(name).view(np.uint8), q.buffer(name).view(np.uint8)), name
+    assert np.array_equal(q_img[0], f_run.render_depth()) and np.array_equal(q_img[1], f_run.render_track())
+    assert np.array_equal(q_img[2], f_run.render_volume(n - 1, zrate, k, 0.75 * util.MU))
+    assert np.abs(f_run.get_pose() - o.get_pose()).max() <= 1e-4 and g.get_error() == 0 and q.get_error() == 0
+    for x in (g, o, f_run, q):
+        x.close()
+
+
+def test_300_frames_queued_against_serial_oracle_with_a_fixed_schedule_floor(hip, kfmod, orc):
+    """300 free-running frames of BASELINE configs[1] (640x480, 256^3, -r 2) through the QUEUED path against the oracle in serial
+    order: position within 1e-4 m and verdict flags equal on EVERY frame.  Per-voxel TSDF: the fraction of voxels off by more than
+    1e-4 is held against the reference's own CPP-vs-OpenMP floor - its OpenMP reduction (cpp:295-296) emulated with a FIXED static
+    schedule and combine order for T in {2, 4, 8, 16} threads (oracle `reduce emulation`, pinned to libgomp at T = 2 by
+    tests/test_oracle_cpu.py), maximum over T - so the bound no longer depends on libgomp's arrival order or the host's cores.
+    Both sides of the comparison are deterministic."""
+    n = 300
+    s = util.synth.make_stream(n, W, H)
+    k = list(s.k)
+    res = (256, 256, 256)
+
+    def off_by_more_than_1e4(a, b):
+        d = np.abs(a[..., 0].astype(np.int32) - b[..., 0].astype(np.int32))
+        return float(np.mean(d > 3)), float(np.mean(a[..., 1] != b[..., 1]))      # 1e-4 of the TSDF range = 3.3 of 32766
+
+    def oracle_run(threads, per_frame=None):
+        orc.set_reduce_emulation(threads)
+        try:
+            o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+            for f in range(n):
+                o.preprocessing(s.depth_mm[f]); to = o.tracking(k, util.ICP_THRESHOLD, 1, f); io = o.integration(k, 2, util.MU, f); o.raycasting(k, util.MU, f)
+                if per_frame:
+                    per_frame(f, o.get_pose(), bool(to), bool(io))
+            vol = o.buffer("volume").copy()
+            o.close()
+            return vol
+        finally:
+            orc.set_reduce_emulation(0)
+
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    for f in range(n):
+        g.compute_frame(s.depth_mm[f], (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)        # queued: no host round trip per frame
+    poses, tracked, integrated = g.frame_log(n)
+    assert g.barrier_timeouts() == 0 and g.get_error() == 0
+    vol_hip = g.buffer("volume")
+    g.close()
+
+    worst = [0.0]
+
+    def check(f, pose, tr, it):
+        worst[0] = max(worst[0], float(np.abs(poses[f] - pose).max()))
+        assert (bool(tracked[f]), bool(integrated[f])) == (tr, it), f
+    vol_serial = oracle_run(0, check)
+    assert worst[0] <= 1e-4, worst[0]
+    assert int(tracked.sum()) == n - 4                                     # every frame from 4 on tracks on this stream
+    hip_frac, hip_w = off_by_more_than_1e4(vol_hip, vol_serial)
+    floors = {}
+    for T in (2, 4, 8, 16):
+        floors[T] = off_by_more_than_1e4(oracle_run(T), vol_serial)
+    floor_frac, floor_w = max(v[0] for v in floors.values()), max(v[1] for v in floors.values())
+    print("300 frames: max |pose - oracle| %.3g; voxels off by > 1e-4: HIP %.3g (weights %.3g); fixed-schedule OpenMP floor by threads %s"
+          % (worst[0], hip_frac, hip_w, {T: "%.3g" % v[0] for T, v in floors.items()}))
+    assert floor_frac > 0
+    assert hip_frac <= 2.0 * floor_frac, (hip_frac, floors)
+    assert hip_w <= 2.0 * max(floor_frac, floor_w), (hip_w, floors)
+
+
+def test_host_input_soak_in_the_drivers_shape(hip, kfmod):
+    """The queued loop fed from pageable host memory (what Kfusion::computeFrame(const ushort*) means, kernels.h:158-162) in the
+    shape the driver's bench runs it - a short warm-up, then frames back to back, the caller's buffer overwritten right after every
+    call - over enough frames to wrap the upload rings many times: every buffer equal to the device-resident run, bit for bit."""
+    import torch
+    n = 70
+    s = util.synth.make_stream(n, W, H)
+    k = list(s.k)
+    res = (128, 128, 128)
+    d_depth = torch.from_numpy(s.depth_mm.view(np.int16)).cuda()
+    a = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    b = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    scratch = np.zeros((H, W), np.uint16)
+    for f in range(n):
+        a.compute_frame(d_depth.data_ptr() + f * W * H * 2, (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        scratch[...] = s.depth_mm[f]
+        b.compute_frame(scratch, (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        scratch[...] = 0xFFFF                                              # the caller's buffer is its own again on return
+        if f in (4, 37):                                                   # a synchronisation in the middle of a ring round
+            b.synchronise()
+    pa, pb = a.frame_log(n), b.frame_log(n)
+    assert same_bits(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and np.array_equal(pa[2], pb[2])
+    for name in ("volume", "vertex", "normal", "trackResult", "floatDepth", "scaledDepth0", "inputNormal2"):
+        assert np.array_equal(a.buffer(name).view(np.uint8), b.buffer(name).view(np.uint8)), name
+    assert a.get_error() == 0 and b.get_error() == 0 and int(pa[1].sum()) == n - 4
+    a.close(); b.close()
+
+
+def test_two_threads_each_with_a_context_and_synchronise_all(hip, kfmod):
+    """INTEGRATION.md allows several contexts driven from separate threads, and the argument-less
+    synchroniseDevices() of the reference (kfh_synchronise_all) visits EVERY context of the process - so one thread's call meets
+    the other thread in the middle of kfh_compute_frame / render calls on its own context.  Every C-ABI entry now holds its
+    context's lock; two threads hammering their contexts and kfh_synchronise_all must leave exactly the bits of a
+    single-threaded run (ctypes releases the GIL during the calls, so the threads do overlap inside the library)."""
+    n = 40
+    s = util.synth.make_stream(n, 320, 240)
+    k = list(s.k)
+    res = (64, 64, 64)
+
+    def drive(ctx, out, sync_all):
+        img = np.zeros((240, 320, 4), np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        try:
+            for f in range(n):
+                ctx.compute_frame(s.depth_mm[f], (320, 240), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+                ctx.L.kfh_render_track(ctx.h, img.ctypes.data_as(u8), 320, 240)
+                if sync_all:
+                    ctx.L.kfh_synchronise_all()
+                if f % 7 == 3:
+                    ctx.get_position()
+            ctx.synchronise()
+            out.append((ctx.frame_log(n), ctx.buffer("volume").copy(), ctx.buffer("vertex").copy(), img.copy()))
+        except Exception as e:      # noqa: BLE001
+            out.append(e)
+
+    single = []
+    c0 = kfmod.Kfusion((320, 240), res, util.VOL_DIM, s.init_pos)
+    drive(c0, single, False)
+    c0.close()
+    assert not isinstance(single[0], Exception), single[0]
+    ctxs = [kfmod.Kfusion((320, 240), res, util.VOL_DIM, s.init_pos) for _ in range(2)]
+    outs = [[], []]
+    threads = [threading.Thread(target=drive, args=(ctxs[i], outs[i], True)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck inside the library"
+    for i in range(2):
+        assert outs[i] and not isinstance(outs[i][0], Exception), outs[i]
+        (log, vol, vertex, img), (log1, vol1, vertex1, img1) = outs[i][0], single[0]
+        assert same_bits(log[0], log1[0]) and np.array_equal(log[1], log1[1]) and np.array_equal(log[2], log1[2])
+        assert np.array_equal(vol, vol1) and same_bits(vertex, vertex1) and np.array_equal(img, img1)
+        assert ctxs[i].get_error() == 0
+        ctxs[i].close()

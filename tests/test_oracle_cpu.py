@@ -209,3 +209,39 @@ def test_dump_volume_layout(orc, tmp_path):
     assert kf.dump_volume(path) == 0
     assert np.array_equal(np.fromfile(path, np.int16), kf.buffer("volume")[..., 0].reshape(-1))   # cpp:1022-1026
     kf.close()
+
+
+def test_fixed_schedule_emulation_of_the_references_openmp_reduction(orc):
+    """oracle mode "reduce emulation": the reference's `#pragma omp parallel for reduction(+:sums0..31)` (cpp:295-296) with T threads
+    under gcc's static schedule and a FIXED combine order, computed serially.  Pins: one thread is the serial chain bit for bit;
+    two threads equal the real libgomp run bit for bit (with two shares the combine order cannot matter: fp addition commutes);
+    more threads re-associate further, deterministically."""
+    s = util.small_stream(8)
+
+    def run(emulated, real_mode=False, threads=None, omp=True):
+        orc.set_reduce_emulation(emulated, omp=omp)
+        if omp:
+            orc.set_omp_reduce_mode(real_mode)
+            if threads:
+                orc.set_omp_threads(threads)
+        try:
+            kf, _ = util.run_oracle(orc, s, 8, vol_res=(48, 48, 48), omp=omp)
+            out = (kf.get_pose().copy(), kf.buffer("reduction").copy())
+            kf.close()
+            return out
+        finally:
+            orc.set_reduce_emulation(0, omp=omp)
+            if omp:
+                orc.set_omp_reduce_mode(False)
+
+    serial = run(0, omp=False)
+    for omp in (False, True):
+        one = run(1, omp=omp)
+        assert np.array_equal(one[0].view(np.uint32), serial[0].view(np.uint32)) and np.array_equal(one[1].view(np.uint32), serial[1].view(np.uint32))
+    two, real_two = run(2), run(0, real_mode=True, threads=2)
+    assert np.array_equal(two[0].view(np.uint32), real_two[0].view(np.uint32))
+    assert np.array_equal(two[1].view(np.uint32), real_two[1].view(np.uint32))
+    assert not np.array_equal(two[1].view(np.uint32), serial[1].view(np.uint32))          # ... and it IS a different association
+    sixteen, again = run(16), run(16, omp=False)
+    assert np.array_equal(sixteen[1].view(np.uint32), again[1].view(np.uint32))           # no dependence on the build or the host's threads
+    assert np.abs(sixteen[0] - serial[0]).max() < 1e-5 and np.array_equal(sixteen[1][0, 28:], serial[1][0, 28:])   # counters are exact
