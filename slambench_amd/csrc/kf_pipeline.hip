@@ -608,8 +608,19 @@ static const uint16_t *stage_input_queued(kfh_context *c, const uint16_t *host, 
     if (slot % ROUND == 0 && !HIP_TRY(hipEventSynchronize(c->q_round[slot / ROUND]))) return nullptr;
     std::memcpy(c->q_host[slot], host, bytes);
     bool ok = HIP_TRY(hipMemcpyAsync(c->q_dev[slot], c->q_host[slot], bytes, hipMemcpyHostToDevice, c->copy_stream));
-    ok = ok && HIP_TRY(hipEventRecord(c->q_copied[slot], c->copy_stream));
-    ok = ok && HIP_TRY(hipStreamWaitEvent(c->stream, c->q_copied[slot], 0));
+    // Who waits for the copy.  The calling thread does (KFH_UPLOAD_WAIT=host, default): it is several frames ahead of the device and
+    // has the ~25 us to spare, and the compute stream then carries nothing for the upload.  Letting the compute stream wait instead
+    // (KFH_UPLOAD_WAIT=device: an event behind the copy, a barrier packet in front of the launches that read the frame) keeps the
+    // host free but costs every frame ~9 us of device time even though the copy finished long before - measured, cfg2: host-input
+    // rate 5340 against 5640 frames/s device-resident at 300 steps, 5050 against 5300 in the driver's 20-step shape; with the host
+    // waiting 5645 against 5645 and 5260 against 5330 (profiles/r03_upload_ab.txt).
+    static const bool device_wait = [] { const char *e = getenv("KFH_UPLOAD_WAIT"); return e && e[0] == 'd'; }();
+    if (!device_wait) {
+        ok = ok && HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    } else {
+        ok = ok && HIP_TRY(hipEventRecord(c->q_copied[slot], c->copy_stream));
+        ok = ok && HIP_TRY(hipStreamWaitEvent(c->stream, c->q_copied[slot], 0));
+    }
     c->q_last = slot;       // kfh_compute_frame records the round's event once the readers of its last buffer are queued
     return ok ? c->q_dev[slot] : nullptr;
 }
