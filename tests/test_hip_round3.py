@@ -76,7 +76,7 @@ def test_300_frames_queued_against_serial_oracle_with_a_fixed_schedule_floor(hip
     """300 free-running frames of BASELINE configs[1] (640x480, 256^3, -r 2) through the QUEUED path against the oracle in serial
     order: position within 1e-4 m and verdict flags equal on EVERY frame.  Per-voxel TSDF: the fraction of voxels off by more than
     1e-4 is held against the reference's own CPP-vs-OpenMP floor - its OpenMP reduction (cpp:295-296) emulated with a FIXED static
-    schedule and combine order for T in {2, 4, 8, 16} threads (oracle `reduce emulation`, pinned to libgomp at T = 2 by
+    schedule and combine order for T = 2 and T = 16 threads (4 and 8 were measured too: 9.0e-4 and 1.12e-3 against 1.12e-3 and 1.02e-3) (oracle `reduce emulation`, pinned to libgomp at T = 2 by
     tests/test_oracle_cpu.py), maximum over T - so the bound no longer depends on libgomp's arrival order or the host's cores.
     Both sides of the comparison are deterministic."""
     n = 300
@@ -120,7 +120,7 @@ def test_300_frames_queued_against_serial_oracle_with_a_fixed_schedule_floor(hip
     assert int(tracked.sum()) == n - 4                                     # every frame from 4 on tracks on this stream
     hip_frac, hip_w = off_by_more_than_1e4(vol_hip, vol_serial)
     floors = {}
-    for T in (2, 4, 8, 16):
+    for T in (2, 16):
         floors[T] = off_by_more_than_1e4(oracle_run(T), vol_serial)
     floor_frac, floor_w = max(v[0] for v in floors.values()), max(v[1] for v in floors.values())
     print("300 frames: max |pose - oracle| %.3g; voxels off by > 1e-4: HIP %.3g (weights %.3g); fixed-schedule OpenMP floor by threads %s"
