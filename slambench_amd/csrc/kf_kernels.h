@@ -34,10 +34,6 @@ struct DevState {
     unsigned barrier_timeouts;               // workgroups that gave up waiting there (never, unless the device is hogged)
     unsigned timeouts_at_track_begin;        // barrier_timeouts when the current frame's tracking began
     unsigned failed_frames;                  // frames whose ICP loop saw a barrier time-out: pose rolled back, reported untracked
-    // scheduling feedback of the generic step launches, kept here by the launches of a frame and copied to the host-visible words by
-    // the FIRST launch of the next frame's loop (a store to host memory has to be acknowledged over PCIe before its kernel can end:
-    // in every launch that was +2.7 us each, profiles/r03_sweeps.md): [0] = 1 + iterations of the last closed loop, [1 + g] = 1 + level of launch g
-    unsigned icp_fb[1 + 48];
 };
 
 // Upper bounds over the whole volume of |pos.*| (pos = inverse(pose) * voxel centre: every voxel is within `far` of the
@@ -70,8 +66,7 @@ __host__ __device__ inline void integrate_bounds_matrix(const M4 &pose, const M4
 }
 
 // state entering ICP iteration `it` (pose to associate with, per-level converged flags) and whether it ran
-// (level / it_in_level / finished / n_executed: the schedule of the generic step launches, see k_icp_step)
-struct IcpState { M4 pose; int done[KFH_MAX_LEVELS]; int executed; int level, it_in_level, finished; int n_executed; int pad[3]; };
+struct IcpState { M4 pose; int done[KFH_MAX_LEVELS]; int executed; int pad[3]; };
 
 struct FrameLogEntry { M4 pose; int tracked; int integrated; int frame; int pad; };
 
@@ -125,26 +120,6 @@ struct SideWork {
 // OP_TRACK_BEGIN of the next queued frame, carried by a raycast launch (kf_kernels.hip, SkipGrid::next_state)
 struct NextTrackBegin { DevState *state; float k[4]; unsigned frame, tracking_rate; };
 
-// Generic ICP step launches (k_icp_step): launch g of a frame's loop runs whichever iteration is due - the level and the
-// iteration number come from the record the previous launch left, not from the launch's position in the queue - so a level
-// that converges early costs no "find out that it is over" launch and no empty ones; the first launch that finds the loop
-// finished closes it (final pose, `end_ops`, frame log, feedback word).  `icp_finish` ends the queue: it runs whatever is
-// still due (rare: more iterations than step launches were queued) in one launch with a grid barrier between iterations.
-struct IcpLevelArgs { const float4 *inV, *inN; unsigned w, h, nblocks; int its; };
-struct IcpLoopArgs {
-    DevState *st; IcpState *iters; float *part[2]; int *result_map;
-    int n_levels;
-    IcpLevelArgs lv[KFH_MAX_LEVELS];
-    const float4 *refV, *refN; unsigned refW, refH;
-    float icp_threshold, dist_threshold, normal_threshold;
-    FrameLogEntry *log; int end_ops; ControlArgs ca;
-    // host-visible words, or nullptr: a copy of DevState::icp_fb as the previous frame's loop left it ([0] = 1 + iterations it
-    // executed, [1 + g] = 1 + level that step launch g ran, 0: none; g < KFH_ICP_FEEDBACK_STEPS).  Scheduling hints only.
-    unsigned *feedback;
-    unsigned long long *wall;    // debugging (KFH_ICP_WALL): 4 stamps of the 100 MHz wall clock per launch of the loop (block 0), or nullptr
-};
-#define KFH_ICP_FEEDBACK_STEPS 48
-static_assert(sizeof(((DevState *)0)->icp_fb) == (1 + KFH_ICP_FEEDBACK_STEPS) * sizeof(unsigned), "feedback words");
 namespace launch {
 // first kernel launch the runtime rejected since the last call ("launch of k_x failed: ..."), or nullptr
 const char *take_launch_error();
@@ -188,11 +163,6 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
               FrameLogEntry *log, int final_ops, const ControlArgs *ca, hipStream_t s);   // ca != nullptr: also does icp_final's work
-// icp_grid: ICP workgroups of the launch (0 or anything above the bound = the bound: the finest level launch g can reach)
-// prev_rows: partial rows of the previous launch worth requesting ahead of its record (0 = all a launch can leave); a hint too
-unsigned icp_step_grid_bound(const IcpLoopArgs &loop, int g);
-void icp_step(const IcpLoopArgs &loop, int g, unsigned icp_grid, unsigned prev_rows, const SideWork *side, hipStream_t s);
-void icp_finish(const IcpLoopArgs &loop, int g, bool may_iterate, hipStream_t s);
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

@@ -1196,292 +1196,6 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_py
     }
 }
 
-// ---- generic step launches ----------------------------------------------------------------------------------------
-// The launches above are tied to a (level, iteration) slot of the reference loop (cpp:950-967): all 19 slots are queued, a
-// level that converges leaves behind one launch that runs the prologue only to find that out (~5 us) and slots that exit at
-// once (~3.4 us each), and the late level-0 slots share k_icp_tail - on the benchmark stream ~33 us per frame of launches that
-// associate nothing (profiles/r02_timeline_cfg2.txt).  A STEP launch is not tied to a slot: launch g reads the record launch
-// g-1 left ({pose, converged flags, level, iteration number, finished}), adds up its partial rows and solves (if it ran), then
-// runs WHICHEVER iteration the reference loop would run next - the next one of the same level, or the first of the next finer
-// level when the level converged or used up its iterations.  The executed iterations, their blocks, pixels and sums are exactly
-// those of the slot launches (same bits); only the queue shrinks: the host queues as many step launches as recent frames
-// needed (feedback word) and the finish launch covers the rare frame that needs more.  The first launch that finds the loop
-// finished closes it (k_icp_final's job).  Every launch has 256 ICP blocks; those beyond the due level's block count leave
-// after the (redundant, bit-identical) prologue.
-struct IcpStepArgs {
-    IcpLoopArgs loop;
-    int g;                                // launch index within the frame's loop
-    unsigned icp_grid;                    // blocks of this launch that belong to the ICP step (side-job blocks follow)
-    unsigned prev_rows;                   // partial rows of launch g-1 requested ahead of its record (icp_step_enter)
-    unsigned *ray_order, *ray_cost;       // dispatch sort carried by the last block (nullptr = none)
-    unsigned ray_tiles_x, ray_tiles_y, order_mode;
-    unsigned long long *trace;
-};
-
-// lv: the per-level arguments, copied from the kernel arguments when the block starts - which level a launch runs is only known
-// after the previous launch's record has been read, and a kernel-argument load at an index that is known that late is a dependent
-// scalar round trip (~0.5 us each, three in a row on the path of every launch); from LDS it is ~100 cycles
-struct IcpStepShared { int level, it_in_level, finished, prev_level, prev_it, n_executed, was_finished; IcpLevelArgs lv[KFH_MAX_LEVELS]; };
-
-// state entering step g: the solve of step g-1 (if it ran), then the iteration that is due.  Returns true if one is.
-template <bool COHERENT>
-__device__ __forceinline__ bool icp_step_enter(IcpShared &sh, IcpStepShared &ss, const IcpLoopArgs &L, int g, bool writer,
-                                               unsigned prev_rows, unsigned long long *trace = nullptr) {
-    // everything the prologue takes from the kernel arguments in ONE scalar round trip: written where they are used, these are
-    // five dependent loads in a row (~1 500 cycles at the head of every launch, profiles/r03_sweeps.md); the empty statement
-    // "uses" them all here, so that the compiler requests them together
-    DevState *__restrict__ st = L.st;
-    IcpState *const iters = L.iters;
-    float *const part0 = L.part[0], *const part1 = L.part[1];
-    unsigned *const feedback = L.feedback;
-    unsigned long long *const wall = L.wall;
-    const float icp_threshold = L.icp_threshold;
-    asm volatile("" : : "s"(st), "s"(iters), "s"(part0), "s"(part1), "s"(feedback), "s"(wall), "s"(icp_threshold), "s"(g), "s"(prev_rows), "s"(trace));
-    ICP_STAMP(0);
-#define ICP_WALL(i) do { if (wall && writer && threadIdx.x == 0) wall[4 * g + (i)] = wall_clock64(); } while (0)
-    ICP_WALL(0);
-    // the partial rows the previous launch is expected to have left (`prev_rows`: the block count of the level recent frames ran
-    // there) are requested before the record that says how many really count: one round trip on the path of every executed
-    // iteration instead of two; rows beyond the expectation, if the record asks for them, are fetched afterwards
-    static_assert(sizeof(IcpLevelArgs) == 32 && sizeof(IcpLevelArgs) * KFH_MAX_LEVELS == 256, "64 words");
-    if (g == 0 && writer && feedback && threadIdx.x >= 64 && threadIdx.x < 64 + 1 + KFH_ICP_FEEDBACK_STEPS)
-        __hip_atomic_store(feedback + (threadIdx.x - 64), st->icp_fb[threadIdx.x - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (see DevState::icp_fb)
-    const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
-    constexpr int G = ICP_THREADS / 32, PRE = 8;
-    const float *partials_prev = ((g + 1) & 1) ? part1 : part0;
-    // the level table goes to LDS (IcpStepShared::lv): requested first, stored once the rows have been requested too
-    const bool stager = threadIdx.x >= 128 && threadIdx.x < 192;
-    unsigned lv_word = 0;
-    if (stager) lv_word = reinterpret_cast<const unsigned *>(L.lv)[threadIdx.x - 128];
-    float pre[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const unsigned b = (unsigned)gq + (unsigned)k * G;
-        pre[k] = (g == 0 || b >= prev_rows) ? 0.f
-                        : (COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                    : partials_prev[(size_t)b * 32 + c]);
-    }
-    if (stager) reinterpret_cast<unsigned *>(ss.lv)[threadIdx.x - 128] = lv_word;
-    if (threadIdx.x == 0) {
-        if (g == 0) {
-            sh.pose = st->pose;
-            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = st->level_done[l];
-            sh.prev_executed = 0;
-            ss.prev_level = L.n_levels - 1; ss.prev_it = -1; ss.was_finished = 0; ss.n_executed = 0;
-            if (writer) for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->tail_barrier[l] = 0;   // (the finish launch's counters: none is running)
-        } else {
-            IcpState prev;
-            if (COHERENT) {
-                static_assert(sizeof(IcpState) % 4 == 0, "word-wise copy");
-                const unsigned *src = reinterpret_cast<const unsigned *>(iters + (g - 1));
-                unsigned *dst = reinterpret_cast<unsigned *>(&prev);
-                for (unsigned w = 0; w < sizeof(IcpState) / 4; ++w) dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                prev = iters[g - 1];
-            }
-            sh.pose = prev.pose;
-            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = prev.done[l];
-            sh.prev_executed = prev.executed;
-            ss.prev_level = prev.level; ss.prev_it = prev.it_in_level; ss.was_finished = prev.finished; ss.n_executed = prev.n_executed;
-        }
-    }
-    __syncthreads();
-    ICP_STAMP(1);
-    if (sh.prev_executed) {      // uniform
-        const unsigned prev_nblocks = ss.lv[ss.prev_level].nblocks;
-        float acc = 0.f;
-        if (prev_nblocks > prev_rows) {      // (uniform; rare: the previous launch ran a finer level than expected) the rows not requested ahead
-#pragma unroll
-            for (int k = 0; k < PRE; ++k) {
-                const unsigned b = (unsigned)gq + (unsigned)k * G;
-                if (b >= prev_rows && b < prev_nblocks)
-                    pre[k] = COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PRE; ++k)
-            if ((unsigned)gq + (unsigned)k * G < prev_nblocks) acc += pre[k];
-        for (unsigned b = (unsigned)gq + PRE * G; b < prev_nblocks; b += G)     // (more than 256 blocks: KFH_ICP_BLOCKS)
-            acc += COHERENT ? __hip_atomic_load(partials_prev + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials_prev[(size_t)b * 32 + c];
-        sh.sm[gq][c] = acc;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            float v = sh.sm[0][threadIdx.x];
-#pragma unroll
-            for (int k = 1; k < G; ++k) v += sh.sm[k][threadIdx.x];
-            sh.red[threadIdx.x] = v;
-            if (writer) st->reduction[threadIdx.x] = v;
-        }
-        __syncthreads();
-        ICP_STAMP(2);
-        if (threadIdx.x == 0) {
-            M4 pose = sh.pose;
-            bool fast = true;
-            const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast, sh.jacobi_ws);
-            sh.pose = pose;
-            if (converged) sh.done[ss.prev_level] = 1;
-            if (writer) {
-                atomicAdd(&st->icp_iterations, 1ull);
-                atomicAdd(&st->icp_level_iterations[ss.prev_level], 1ull);
-                if (!fast) atomicAdd(&st->solve_fallbacks, 1ull);
-            }
-        }
-        ICP_STAMP(3);
-    }
-    if (threadIdx.x == 0) {
-        // cpp:950-967: `for level (coarse to fine) for i < iterations[level] { track; reduce; if (updatePose) break; }`
-        int lvl = ss.prev_level, j = ss.prev_it + 1;
-        bool fin = ss.was_finished != 0;
-        if (!fin) {
-            while (lvl >= 0 && (sh.done[lvl] || j >= ss.lv[lvl].its)) { --lvl; j = 0; }
-            fin = lvl < 0;
-        }
-        ss.level = fin ? 0 : lvl; ss.it_in_level = fin ? 0 : j; ss.finished = fin ? 1 : 0;
-        sh.executed = fin ? 0 : 1;
-        if (writer) {
-            IcpState &o = iters[g];
-            o.pose = sh.pose;
-            for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-            o.executed = sh.executed; o.level = ss.level; o.it_in_level = ss.it_in_level; o.finished = ss.finished;
-            o.n_executed = ss.n_executed + sh.executed;
-            // (frames without a reference yet - 0 to 3 - run one iteration per level, cpp:977: not what the queue should be sized for)
-            if (st->track.have_reference && g < KFH_ICP_FEEDBACK_STEPS)      // which level this position of the queue ran (0: none), for the host's launch sizes
-                st->icp_fb[1 + g] = sh.executed ? (unsigned)ss.level + 1u : 0u;
-            if (fin && !ss.was_finished) {
-                // this launch is the first to find the loop over: final pose and flags, then the control operations that follow
-                // tracking (k_icp_final's job), and the iteration count for the host's queue length
-                st->pose = sh.pose;
-                for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = sh.done[l];
-                control_ops(st, L.log, L.end_ops, L.ca);
-                if (st->track.have_reference) st->icp_fb[0] = (unsigned)ss.n_executed + 1u;
-            }
-        }
-    }
-    __syncthreads();
-    ICP_STAMP(4);
-    ICP_WALL(1);
-#undef ICP_WALL
-    return sh.executed != 0;
-}
-
-// the per-level arguments of the due iteration in the form icp_track_block takes
-__device__ __forceinline__ IcpIterArgs icp_level_view(const IcpLoopArgs &L, const IcpStepShared &ss, unsigned long long *trace) {
-    IcpLevelArgs lv = ss.lv[ss.level];              // (LDS broadcast reads; uniform: moved to scalar registers)
-    {
-        unsigned w[8];
-        __builtin_memcpy(w, &lv, sizeof lv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)w[i]);
-        __builtin_memcpy(&lv, w, sizeof lv);
-    }
-    IcpIterArgs a;
-    a.st = L.st; a.iters = L.iters; a.partials_prev = nullptr; a.partials_out = nullptr; a.result_map = L.result_map;
-    a.it = 0; a.level = ss.level; a.prev_level = ss.level; a.prev_nblocks = 0; a.nblocks = lv.nblocks;
-    a.inV = lv.inV; a.inN = lv.inN; a.inW = lv.w; a.inH = lv.h;
-    a.refV = L.refV; a.refN = L.refN; a.refW = L.refW; a.refH = L.refH;
-    a.icp_threshold = L.icp_threshold; a.dist_threshold = L.dist_threshold; a.normal_threshold = L.normal_threshold;
-    a.trace = trace; a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = a.order_mode = 0;
-    return a;
-}
-
-__device__ __forceinline__ void icp_step_block(IcpShared &sh, IcpStepShared &ss, const IcpStepArgs &a) {
-    if (!icp_step_enter<false>(sh, ss, a.loop, a.g, blockIdx.x == 0, a.prev_rows, a.trace)) return;
-    const IcpIterArgs la = icp_level_view(a.loop, ss, a.trace);
-    // The host sizes the launch for the level recent frames ran at this position (feedback words): usually exactly the due
-    // level's block count.  A coarser level than expected leaves blocks without work; a FINER one makes every block emulate
-    // several (same pixels per emulated block, same partial rows: same bits, only slower) - the result never depends on the grid.
-    for (unsigned vb = blockIdx.x; vb < la.nblocks; vb += a.icp_grid) {
-        icp_track_block(sh, la, vb, a.loop.part[a.g & 1]);
-        if (vb + a.icp_grid < la.nblocks) __syncthreads();      // block_reduce_store's LDS rows are reused
-    }
-    if (a.loop.wall && blockIdx.x == 0 && threadIdx.x == 0) a.loop.wall[4 * a.g + 2] = wall_clock64();
-}
-
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_step(IcpStepArgs a) {
-    __shared__ IcpShared sh;
-    __shared__ IcpStepShared ss;
-    icp_step_block(sh, ss, a);
-}
-
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_step_order(IcpStepArgs a) {
-    __shared__ IcpShared sh;
-    __shared__ IcpStepShared ss;
-    __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.icp_grid) { icp_step_block(sh, ss, a); return; }
-    ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
-}
-
-template <bool FD>
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_step_bilateral(IcpStepArgs a, SideBilateral sb) {
-    __shared__ IcpShared sh;
-    __shared__ IcpStepShared ss;
-    __shared__ float tiles[SIDE_TEAMS][PBY + 2 * PR][PBX + 2 * PR + 1];
-    __shared__ double exp_tab[32];
-    __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.icp_grid) { icp_step_block(sh, ss, a); return; }
-    const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
-    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
-    const unsigned side = blockIdx.x - a.icp_grid, nside = gridDim.x - a.icp_grid - order_blocks;
-    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    if (threadIdx.x < 32) exp_tab[threadIdx.x] = __builtin_bit_cast(double, kExp2fTable[threadIdx.x]);
-    const unsigned tiles_x = (sb.W + PBX - 1) / PBX;
-    const unsigned rounds = (sb.count + nside * SIDE_TEAMS - 1) / (nside * SIDE_TEAMS);
-    for (unsigned r = 0; r < rounds; ++r) {      // (same tile -> block / team assignment as k_icp_iter_bilateral)
-        const unsigned i = (r * SIDE_TEAMS + team) * nside + side;
-        const bool active = i < sb.count;
-        const unsigned t = sb.first + i;
-        bilateral_block<true, FD>(tiles[team], exp_tab, (int)(t % tiles_x), (int)(t / tiles_x), tid, active, sb.floatDepth, sb.out, sb.in,
-                                  sb.W, sb.H, sb.inW, sb.ratio, sb.g, sb.e_d_squared_2, sb.rcp);
-        __syncthreads();
-    }
-}
-
-template <int NLEV>
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_step_pyramid(IcpStepArgs a, SidePyramid sp) {
-    __shared__ IcpShared sh;
-    __shared__ IcpStepShared ss;
-    __shared__ float lds[PYR_SIDE_TEAMS][pyr_lds_floats<NLEV>()];
-    __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.icp_grid) { icp_step_block(sh, ss, a); return; }
-    const unsigned order_blocks = a.ray_order ? 1u : 0u;
-    if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
-    const unsigned side = blockIdx.x - a.icp_grid, nside = gridDim.x - a.icp_grid - order_blocks;
-    const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
-    constexpr int TEAM_THREADS = ICP_THREADS / PYR_SIDE_TEAMS;
-    const int team = (int)threadIdx.x / TEAM_THREADS, tid = (int)threadIdx.x % TEAM_THREADS;
-    const unsigned rounds = (sp.count + nside * PYR_SIDE_TEAMS - 1) / (nside * PYR_SIDE_TEAMS);
-    for (unsigned r = 0; r < rounds; ++r) {      // (as k_icp_iter_pyramid)
-        const unsigned i = (r * PYR_SIDE_TEAMS + (unsigned)team) * nside + side;
-        const unsigned t = sp.first + i;
-        const bool active = i < sp.count;
-        pyramid_block<NLEV, TEAM_THREADS>(sp.a, lds[team], active ? (int)(t % tiles_x) : (int)tiles_x, active ? (int)(t / tiles_x) : 0, tid);
-        __syncthreads();
-    }
-}
-
-// End of the queue of step launches: whatever the loop still owes - usually nothing, or the solve of the last step - then the
-// closing operations if no step launch got there.  Iterations that do run here are emulated block by block by at most
-// ICP_TAIL_BLOCKS workgroups with a grid barrier in between, exactly like k_icp_tail (same bits, several times slower, rare).
-struct IcpFinishArgs { IcpLoopArgs loop; int g; int max_passes; unsigned *barrier; unsigned *timeouts; unsigned long long timeout_ticks; };
-
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_finish(IcpFinishArgs f) {
-    __shared__ IcpShared sh;
-    __shared__ IcpStepShared ss;
-    const bool writer = blockIdx.x == 0;
-    for (int j = 0; j <= f.max_passes; ++j) {
-        const int g = f.g + j;
-        // (rows ahead of the record only after the first pass: usually the last step launch ran nothing and there is nothing to fetch)
-        const bool run = j == 0 ? icp_step_enter<false>(sh, ss, f.loop, g, writer, 0u) : icp_step_enter<true>(sh, ss, f.loop, g, writer, 256u);
-        if (!run || j == f.max_passes) return;       // (max_passes = iterations the queue can still owe: never reached while one is due)
-        const IcpIterArgs la = icp_level_view(f.loop, ss, nullptr);
-        for (unsigned vb = blockIdx.x; vb < la.nblocks; vb += gridDim.x) {
-            icp_track_block(sh, la, vb, f.loop.part[g & 1]);
-            __syncthreads();                         // block_reduce_store's LDS rows are reused
-        }
-        grid_barrier(f.barrier, (unsigned)(j + 1) * gridDim.x, f.timeouts, f.timeout_ticks);
-    }
-}
-
 // Closes the loop: the update of the last iteration, then the scalar glue that follows tracking (checkPose, integrate
 // gate, raycast pose, frame log) — one launch instead of a solve and a control launch.
 __global__ __launch_bounds__(ICP_THREADS) void k_icp_final(DevState *__restrict__ st, FrameLogEntry *__restrict__ log,
@@ -2674,84 +2388,6 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     t.final_ops = ca ? final_ops : -1; t.log = log;
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
     k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t); launched("k_icp_tail");
-}
-
-// grid of step launch g: the finest level it can possibly run (every level runs at least one iteration, so level n_levels-1-k
-// cannot start before launch k) decides how many ICP blocks the launch needs
-static unsigned step_icp_grid(const IcpLoopArgs &loop, int g) {
-    unsigned nb = 1;
-    const int lowest = loop.n_levels - 1 - g > 0 ? loop.n_levels - 1 - g : 0;
-    for (int l = lowest; l < loop.n_levels; ++l) nb = loop.lv[l].nblocks > nb ? loop.lv[l].nblocks : nb;
-    return nb;
-}
-
-unsigned icp_step_grid_bound(const IcpLoopArgs &loop, int g) { return step_icp_grid(loop, g); }
-
-void icp_step(const IcpLoopArgs &loop, int g, unsigned icp_grid, unsigned prev_rows, const SideWork *side, hipStream_t s) {
-    IcpStepArgs a;
-    const unsigned bound = step_icp_grid(loop, g), prev_bound = g > 0 ? step_icp_grid(loop, g - 1) : 0;
-    a.loop = loop; a.g = g; a.icp_grid = (icp_grid >= 1 && icp_grid < bound) ? icp_grid : bound;
-    a.prev_rows = (prev_rows >= 1 && prev_rows < prev_bound) ? prev_rows : prev_bound;
-    a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0; a.order_mode = 0; a.trace = nullptr;
-    const unsigned nblocks = a.icp_grid;
-    if (side && side->ray_order) { a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode; }
-    const unsigned extra = a.ray_order ? 1u : 0u;
-    if (side && side->kind == SideWork::BILATERAL && side->count) {
-        SideBilateral sb;
-        sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
-        sb.inW = side->inW; sb.ratio = side->ratio; sb.g = side->gauss; sb.e_d_squared_2 = side->e_d * side->e_d * 2;
-        const bool fd = divisor_verified(sb.e_d_squared_2);
-        sb.rcp = fd ? 1.0f / sb.e_d_squared_2 : 0.f;
-        sb.first = side->first; sb.count = side->count;
-        const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
-        if (fd) k_icp_step_bilateral<true><<<grid, ICP_THREADS, 0, s>>>(a, sb);
-        else k_icp_step_bilateral<false><<<grid, ICP_THREADS, 0, s>>>(a, sb);
-        launched("k_icp_step_bilateral");
-        return;
-    }
-    if (side && side->kind == SideWork::PYRAMID && side->count) {
-        SidePyramid sp;
-        for (int l = 0; l < PYR_MAX_LEVELS; ++l) {
-            const bool on = l < side->n_levels;
-            sp.a.scaled[l] = on ? side->scaled[l] : nullptr;
-            sp.a.vertex[l] = on ? side->vertex[l] : nullptr;
-            sp.a.normal[l] = on ? side->normal[l] : nullptr;
-            sp.a.stale_normal[l] = on ? side->stale_normal[l] : nullptr;
-            sp.a.invK[l] = on ? side->invK[l] : identity4();
-        }
-        sp.a.W = side->W; sp.a.H = side->H; sp.a.e_d = side->e_d;
-        sp.first = side->first; sp.count = side->count;
-        const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
-        switch (side->n_levels) {
-        case 1: k_icp_step_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 2: k_icp_step_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 3: k_icp_step_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        default: k_icp_step_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        }
-        launched("k_icp_step_pyramid");
-        return;
-    }
-    static WaveTrace wt("KFH_ICP_TRACE");
-    static const int trace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 10; }();
-    if (g == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_step<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_step"); wt.dump(); return; } }
-    if (a.ray_order) { k_icp_step_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a); launched("k_icp_step_order"); return; }
-    k_icp_step<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_step");
-}
-
-void icp_finish(const IcpLoopArgs &loop, int g, bool may_iterate, hipStream_t s) {
-    IcpFinishArgs f;
-    f.loop = loop; f.g = g;
-    int total = 0;
-    for (int l = 0; l < loop.n_levels; ++l) total += loop.lv[l].its > 0 ? loop.lv[l].its : 0;
-    f.max_passes = may_iterate ? (total > g ? total - g : 0) + 1 : 1;     // +1: the pass that applies the last solve and closes
-    f.barrier = &loop.st->tail_barrier[0]; f.timeouts = &loop.st->barrier_timeouts;
-    static const long long ticks_env = [] { const char *e = getenv("KFH_ICP_TAIL_TIMEOUT_TICKS"); return e ? atoll(e) : -1LL; }();
-    f.timeout_ticks = ticks_env >= 0 ? (unsigned long long)ticks_env : 200000000ull;
-    unsigned nb = 1;
-    for (int l = 0; l < loop.n_levels; ++l) nb = loop.lv[l].nblocks > nb ? loop.lv[l].nblocks : nb;
-    // without iterations to run (as many step launches as the loop has iterations) one workgroup is all it takes
-    const unsigned grid = may_iterate && total > g ? (nb < ICP_TAIL_BLOCKS ? nb : ICP_TAIL_BLOCKS) : 1;
-    k_icp_finish<<<grid, ICP_THREADS, 0, s>>>(f); launched("k_icp_finish");
 }
 
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,

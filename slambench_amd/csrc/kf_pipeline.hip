@@ -73,16 +73,6 @@ struct kfh_context {
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
-    // generic step launches (k_icp_step, default; KFH_ICP_GENERIC=0 = one launch per (level, iteration) slot as in rounds 1-2)
-    bool icp_generic = true;
-    bool icp_no_barrier = false;       // a ninth context on one device: as many step launches as the loop has iterations, so that the finish launch never iterates
-    int icp_steps_env = 0;             // KFH_ICP_STEPS: fixed number of step launches per frame (0 = from the feedback words)
-    unsigned *h_icp_fb = nullptr;      // pinned, device-written: [0] = 1 + iterations of the last closed loop, [1 + g] = 1 + level step launch g ran
-    static constexpr int FB_WINDOW = 32;
-    unsigned fb_n[FB_WINDOW] = {};     // the words as sampled at the last FB_WINDOW enqueues (0 = no data yet)
-    unsigned char fb_level[FB_WINDOW][KFH_ICP_FEEDBACK_STEPS] = {};
-    int fb_pos = 0;
-    unsigned long long *d_icp_wall = nullptr;   // KFH_ICP_WALL=<file>: wall-clock stamps of the last frame's loop, dumped when the context is destroyed
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
         bool valid = false;
@@ -369,33 +359,6 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     }
     const int L = (int)c->iterations.size();
     if (!pyramid_ready) enqueue_pyramid(c, k);
-    const bool generic = c->icp_generic && c->icp_total > 0;
-    // generic step launches: how many to queue.  As many as the loops of recent frames executed (feedback words sampled at the
-    // last enqueues: with that many the finish launch has at most the last solve left), all of them for a context that must
-    // not use the grid barrier, KFH_ICP_STEPS when set; before any feedback: four per level as the slot schedule had, less one.
-    int G = 0;
-    unsigned char finest_seen[KFH_ICP_FEEDBACK_STEPS];
-    std::memset(finest_seen, 0, sizeof finest_seen);
-    if (generic) {
-        c->fb_pos = (c->fb_pos + 1) % kfh_context::FB_WINDOW;
-        c->fb_n[c->fb_pos] = c->h_icp_fb[0];
-        for (int g = 0; g < KFH_ICP_FEEDBACK_STEPS; ++g) c->fb_level[c->fb_pos][g] = (unsigned char)c->h_icp_fb[1 + g];
-        unsigned n_max = 0;
-        for (int i = 0; i < kfh_context::FB_WINDOW; ++i) {
-            if (c->fb_n[i] > n_max) n_max = c->fb_n[i];
-            for (int g = 0; g < KFH_ICP_FEEDBACK_STEPS; ++g) {
-                const unsigned char lv = c->fb_level[i][g];      // 1 + level (0 = that launch ran nothing)
-                if (lv && (!finest_seen[g] || lv < finest_seen[g])) finest_seen[g] = lv;
-            }
-        }
-        int dflt = 0;
-        for (int l = 0; l < L; ++l) dflt += c->iterations[l] > 4 ? 4 : (c->iterations[l] > 0 ? c->iterations[l] : 0);
-        G = n_max ? (int)n_max - 1 : dflt - 1;
-        if (c->icp_steps_env > 0) G = c->icp_steps_env;
-        if (c->icp_no_barrier) G = c->icp_total;
-        if (G < L) G = L;
-        if (G > c->icp_total) G = c->icp_total;
-    }
     // side-job plan.  A side block costs what its CU's share of tiles costs (~2.3 us per 32x8 bilateral tile team round,
     // ~8 us of latency for a pyramid tile), and the launch lasts as long as its slowest block, so: the bilateral filter
     // is split over TWO or THREE launches (shorter than the ICP iteration it rides on at 640x480; VALU-bound and longer at 1280x960), the pyramid
@@ -418,8 +381,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
         bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
         int last = -1;
-        auto plain_launch = [&](int v) {    // launch v exists: a step launch, or an iteration slot not folded into a level's tail launch
-            if (generic) return v < G;
+        auto plain_launch = [&](int v) {    // iteration v has a launch of its own (is not folded into a level's tail launch)
             int first = 0;
             for (int level = L - 1; level >= 0; --level) {
                 const int n = c->iterations[level] > 0 ? c->iterations[level] : 0;
@@ -434,77 +396,9 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     }
     const bool placed = next && !bil_its.empty();
     const unsigned bil_tiles = launch::bilateral_tiles(c->W, c->H), pyr_tiles = launch::pyramid_tiles(c->W, c->H);
-    // the side work (next frame's bilateral / pyramid tiles, dispatch sorts) that launch `it` of the loop carries, or nullptr
-    auto pick_side = [&](int it, SideWork &side) -> const SideWork * {
-        const SideWork *sp = nullptr;
-        for (size_t j = 0; placed && j < bil_its.size(); ++j)
-            if (bil_its[j] == it) {
-                const unsigned lo = (unsigned)((unsigned long long)bil_tiles * j / bil_its.size()), hi = (unsigned)((unsigned long long)bil_tiles * (j + 1) / bil_its.size());
-                fill_side_bilateral(c, *next, side, lo, hi - lo);
-                sp = &side;
-            }
-        for (size_t j = 0; placed && j < pyr_its.size(); ++j)
-            if (pyr_its[j] == it) {
-                const unsigned lo = (unsigned)((unsigned long long)pyr_tiles * j / pyr_its.size()), hi = (unsigned)((unsigned long long)pyr_tiles * (j + 1) / pyr_its.size());
-                fill_side_pyramid(c, *next, side, lo, hi - lo);
-                sp = &side;
-            }
-        // The two dispatch sorts (one block each; raycast tiles ~10 us, integrate blocks ~5.5 us) ride on side launches
-        // that last that long anyway: the raycast sort on the pyramid launch (a pyramid tile alone takes ~10 us), the
-        // integrate sort on the first bilateral one; without such launches (no next frame queued) the raycast sort
-        // rides on the first launch and the integrate sort runs alone just before k_integrate.
-        const bool pyramid_later = placed && !pyr_its.empty() && it < pyr_its.front();
-        if (c->ray_order_stale && ((sp && sp->kind == SideWork::PYRAMID) || (sp && sp->kind == SideWork::BILATERAL && !pyramid_later && pyr_its.empty()) ||
-                                   (!placed && !sp && it == 0))) {
-            if (!sp) { std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side; }
-            side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost; side.order_mode = 0;
-            launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
-            c->ray_order_stale = false;
-        } else if (c->int_order_stale && sp && sp->kind == SideWork::BILATERAL && !side.ray_order) {
-            side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
-            side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
-            c->int_order_stale = false;
-        } else if (c->int_order_stale && !placed && !sp && it == 1) {
-            // phase calls (no next frame to carry along): the integrate sort rides on the second launch as the raycast sort
-            // rides on the first, instead of running alone in front of k_integrate
-            std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side;
-            side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
-            side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
-            c->int_order_stale = false;
-        }
-        return sp;
-    };
     prof_begin(c, KFH_PROF_ICP);
     if (!begun) launch::control(c->d_state, c->d_log, OP_TRACK_BEGIN, a, c->stream);
     float *part[2] = {c->d_partials, c->d_partials + (size_t)launch::track_blocks_max() * 32};
-    if (generic) {
-        // cpp:950-967 as G step launches + the finish launch (kf_kernels.hip, "generic step launches")
-        IcpLoopArgs loop;
-        std::memset(&loop, 0, sizeof loop);
-        loop.st = c->d_state; loop.iters = c->d_icp; loop.part[0] = part[0]; loop.part[1] = part[1]; loop.result_map = c->d_result;
-        loop.n_levels = L;
-        for (int l = 0; l < L; ++l) {
-            const unsigned w = level_dim(c->W, l), h = level_dim(c->H, l);
-            loop.lv[l].inV = c->d_inV[l]; loop.lv[l].inN = c->d_inN[l]; loop.lv[l].w = w; loop.lv[l].h = h;
-            loop.lv[l].nblocks = launch::icp_blocks(w, h); loop.lv[l].its = c->iterations[l];
-        }
-        loop.refV = c->d_vertex; loop.refN = c->d_normal; loop.refW = c->W; loop.refH = c->H;
-        loop.icp_threshold = icp_threshold; loop.dist_threshold = dist_threshold; loop.normal_threshold = normal_threshold;
-        loop.log = c->d_log; loop.end_ops = end_ops; loop.ca = a; loop.feedback = c->h_icp_fb; loop.wall = c->d_icp_wall;
-        for (int g = 0; g < G; ++g) {
-            SideWork side;
-            const SideWork *sp = pick_side(g, side);
-            // workgroups of the launch: the block count of the finest level recent frames ran at this position of the queue
-            // (0 = no data: the finest level the position can reach); a wrong guess costs time, never bits
-            unsigned grid = 0, prev_rows = 0;
-            if (g < KFH_ICP_FEEDBACK_STEPS && finest_seen[g] && (int)finest_seen[g] - 1 < L) grid = loop.lv[finest_seen[g] - 1].nblocks;
-            if (g > 0 && g - 1 < KFH_ICP_FEEDBACK_STEPS && finest_seen[g - 1] && (int)finest_seen[g - 1] - 1 < L) prev_rows = loop.lv[finest_seen[g - 1] - 1].nblocks;
-            launch::icp_step(loop, g, grid, prev_rows, sp, c->stream);
-        }
-        launch::icp_finish(loop, G, !c->icp_no_barrier, c->stream);
-        prof_end(c, KFH_PROF_ICP);
-        return placed;
-    }
     int it = 0, prev_level = 0;
     unsigned prev_nb = 0;
     bool closed = false;
@@ -514,7 +408,42 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         const int n_tail = tail_length(c, level), n_plain = c->iterations[level] - n_tail;
         for (int i = 0; i < n_plain; ++i) {
             SideWork side;
-            const SideWork *sp = pick_side(it, side);
+            const SideWork *sp = nullptr;
+            for (size_t j = 0; placed && j < bil_its.size(); ++j)
+                if (bil_its[j] == it) {
+                    const unsigned lo = (unsigned)((unsigned long long)bil_tiles * j / bil_its.size()), hi = (unsigned)((unsigned long long)bil_tiles * (j + 1) / bil_its.size());
+                    fill_side_bilateral(c, *next, side, lo, hi - lo);
+                    sp = &side;
+                }
+            for (size_t j = 0; placed && j < pyr_its.size(); ++j)
+                if (pyr_its[j] == it) {
+                    const unsigned lo = (unsigned)((unsigned long long)pyr_tiles * j / pyr_its.size()), hi = (unsigned)((unsigned long long)pyr_tiles * (j + 1) / pyr_its.size());
+                    fill_side_pyramid(c, *next, side, lo, hi - lo);
+                    sp = &side;
+                }
+            // The two dispatch sorts (one block each; raycast tiles ~10 us, integrate blocks ~5.5 us) ride on side launches
+            // that last that long anyway: the raycast sort on the pyramid launch (a pyramid tile alone takes ~10 us), the
+            // integrate sort on the first bilateral one; without such launches (no next frame queued) the raycast sort
+            // rides on the first launch and the integrate sort runs alone just before k_integrate.
+            const bool pyramid_later = placed && !pyr_its.empty() && it < pyr_its.front();
+            if (c->ray_order_stale && ((sp && sp->kind == SideWork::PYRAMID) || (sp && sp->kind == SideWork::BILATERAL && !pyramid_later && pyr_its.empty()) ||
+                                       (!placed && !sp && it == 0))) {
+                if (!sp) { std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side; }
+                side.ray_order = c->d_ray_order; side.ray_cost = c->d_ray_cost; side.order_mode = 0;
+                launch::ray_tile_grid(c->W, c->H, &side.ray_tiles_x, &side.ray_tiles_y);
+                c->ray_order_stale = false;
+            } else if (c->int_order_stale && sp && sp->kind == SideWork::BILATERAL && !side.ray_order) {
+                side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
+                side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
+                c->int_order_stale = false;
+            } else if (c->int_order_stale && !placed && !sp && it == 1) {
+                // phase calls (no next frame to carry along): the integrate sort rides on the second launch as the raycast sort
+                // rides on the first, instead of running alone in front of k_integrate
+                std::memset(&side, 0, sizeof side); side.kind = SideWork::RAY_ORDER; sp = &side;
+                side.ray_order = c->d_int_order; side.ray_cost = c->d_int_cost; side.order_mode = 1;
+                side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
+                c->int_order_stale = false;
+            }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
                              dist_threshold, normal_threshold, sp, c->stream);
@@ -778,19 +707,11 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
         std::lock_guard<std::mutex> lk(g_registry_mu);
         int live = 0;
         for (const kfh_context *o : g_registry) live += o->device == c->device ? 1 : 0;
-        if (live >= 8) { c->icp_tail_head.assign(1, 0); c->icp_no_barrier = true; }
+        if (live >= 8) c->icp_tail_head.assign(1, 0);
     }
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
-    ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 2) * sizeof(IcpState)));
-    { const char *e = getenv("KFH_ICP_GENERIC"); c->icp_generic = !(e && e[0] == '0'); }
-    { const char *e = getenv("KFH_ICP_STEPS"); c->icp_steps_env = e ? atoi(e) : 0; }
-    ok &= HIP_TRY(hipHostMalloc(&c->h_icp_fb, (1 + KFH_ICP_FEEDBACK_STEPS) * sizeof(unsigned), hipHostMallocDefault));
-    if (ok) std::memset(c->h_icp_fb, 0, (1 + KFH_ICP_FEEDBACK_STEPS) * sizeof(unsigned));
-    if (ok && getenv("KFH_ICP_WALL")) {
-        ok &= HIP_TRY(hipMalloc(&c->d_icp_wall, 4 * 64 * sizeof(unsigned long long)));
-        if (ok) HIP_TRY(hipMemsetAsync(c->d_icp_wall, 0, 4 * 64 * sizeof(unsigned long long), c->stream));
-    }
+    ok &= HIP_TRY(hipMalloc(&c->d_icp, (size_t)(c->icp_total + 1) * sizeof(IcpState)));
     ok &= HIP_TRY(hipMalloc(&c->d_volume, (size_t)res[0] * res[1] * res[2] * 2 * sizeof(int16_t)));
     ok &= HIP_TRY(hipMalloc(&c->d_skip, launch::skip_grid_bytes(res[0], res[1], res[2])));
     ok &= HIP_TRY(hipMalloc(&c->d_ray_order, (size_t)launch::ray_tiles(width, height) * sizeof(unsigned)));
@@ -814,7 +735,6 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     HIP_TRY(hipMemsetAsync(c->d_vertex, 0, P * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_normal, 0, P * sizeof(float4), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_result, 0, P * sizeof(int), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_partials, 0, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float), c->stream));   // (the step launches request rows before they know how many count)
     HIP_TRY(hipMemsetAsync(c->d_log, 0, (size_t)c->log_capacity * sizeof(FrameLogEntry), c->stream));
     std::memset(c->h_state, 0, sizeof(DevState));
     c->h_state->pose = pose;
@@ -873,19 +793,6 @@ void kfh_destroy(kfh_context *c) {
     c->pend.valid = false;   // a frame still deferred is dropped with the context
     if (c->stream) hipStreamSynchronize(c->stream);
     c->pending.clear();      // render read-backs nobody synchronised for are dropped: the caller's buffers may be gone by now
-    if (c->d_icp_wall) {
-        unsigned long long h[4 * 64];
-        if (hipMemcpy(h, c->d_icp_wall, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE *f = fopen(getenv("KFH_ICP_WALL") ? getenv("KFH_ICP_WALL") : "/dev/null", "w")) {
-                unsigned long long t0 = 0;
-                for (int g = 0; g < 64; ++g) if (h[4 * g] && (!t0 || h[4 * g] < t0)) t0 = h[4 * g];
-                for (int g = 0; g < 64; ++g)
-                    if (h[4 * g]) fprintf(f, "launch %2d  entry %8.2f us  prologue done +%6.2f  block 0 done +%6.2f\n", g, (h[4 * g] - t0) * 0.01,
-                                          h[4 * g + 1] ? (h[4 * g + 1] - h[4 * g]) * 0.01 : -1.0, h[4 * g + 2] ? (h[4 * g + 2] - h[4 * g]) * 0.01 : -1.0);
-                fclose(f);
-            }
-        hipFree(c->d_icp_wall);
-    }
     hipFree(c->d_input); hipFree(c->d_floatDepth);
     for (float *p : c->d_scaled) hipFree(p);
     for (float4 *p : c->d_inV) hipFree(p);
@@ -907,7 +814,6 @@ void kfh_destroy(kfh_context *c) {
     for (int r = 0; r < kfh_context::Q_SLOTS / kfh_context::Q_ROUND; ++r) if (c->q_round[r]) hipEventDestroy(c->q_round[r]);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->h_state) hipHostFree(c->h_state);
-    if (c->h_icp_fb) hipHostFree(c->h_icp_fb);
     for (int p = 0; p < KFH_PROF_COUNT; ++p) for (hipEvent_t e : c->prof_events[p]) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;

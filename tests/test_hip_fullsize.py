@@ -178,87 +178,31 @@ np.savez(sys.argv[1], pose=g.get_pose(), vertex=g.buffer("vertex"), normal=g.buf
 """
 
 
-ICP_SCHEDULES = {
-    # one launch per (level, iteration) slot of the reference loop, no shared launches: the plainest schedule, the yardstick
-    "slots": {"KFH_ICP_GENERIC": "0", "KFH_ICP_TAIL_HEAD": "0"},
-    # rounds 1-2: slots, the late iterations of a level in one barrier launch (k_icp_tail) after 4 / after 1 of their own
-    "slots+tail4": {"KFH_ICP_GENERIC": "0", "KFH_ICP_TAIL_HEAD": "4"},
-    "slots+tail1": {"KFH_ICP_GENERIC": "0", "KFH_ICP_TAIL_HEAD": "1"},
-    # round 3 (default): generic step launches, as many as recent frames needed (feedback), then the finish launch
-    "steps": {},
-    "steps19": {"KFH_ICP_STEPS": "19"},     # every iteration has a step launch: the finish launch only closes
-    "steps3": {"KFH_ICP_STEPS": "3"},       # hardly any: the finish launch runs most iterations behind its grid barrier
-    "steps7": {"KFH_ICP_STEPS": "7"},
-}
-
-
 @pytest.mark.parametrize("icp_threshold", [util.ICP_THRESHOLD, 0.0])
-def test_every_icp_launch_schedule_leaves_the_same_bits(hip, kfmod, stream, monkeypatch, icp_threshold):
-    """How the iterations of the reference loop (cpp:950-967) are cut into launches is a scheduling matter: slot launches, slot
-    launches with k_icp_tail for the late iterations of a level, generic step launches (k_icp_step: a launch runs whichever
-    iteration is due) with the finish launch (k_icp_finish) behind them.  Every schedule must leave the bits the plainest one
-    leaves - poses, flags, track result, iteration counts, TSDF - when the levels converge early (the common case) and when
-    every queued iteration runs (threshold 0: all 19 per frame; with 3 step launches 16 of them inside the finish launch)."""
+def test_shared_late_iteration_launch_equals_one_launch_per_iteration(hip, kfmod, stream, monkeypatch, icp_threshold):
+    """k_icp_tail runs the late iterations of a pyramid level in one launch, a few workgroups emulating the blocks of an
+    ordinary launch with a grid barrier between iterations.  It must leave the bits one launch per iteration leaves -
+    poses, flags, track result, iteration counts - when the level converges early (the common case: the tail only
+    detects it) and when every queued iteration runs (threshold 0: 6 + 1 x 9 iterations inside tail launches)."""
     k = list(stream.k)
     res = (128, 128, 128)
     runs = {}
-    for name, env in ICP_SCHEDULES.items():
-        for var in ("KFH_ICP_GENERIC", "KFH_ICP_TAIL_HEAD", "KFH_ICP_STEPS"):
-            monkeypatch.delenv(var, raising=False)
-        for var, val in env.items():
-            monkeypatch.setenv(var, val)
+    for head in ("0", "4", "1"):      # 0: no tail launches; 1: every level's iterations 1.. share a launch
+        monkeypatch.setenv("KFH_ICP_TAIL_HEAD", head)
         g = kfmod.Kfusion((W, H), res, util.VOL_DIM, stream.init_pos)
         for f in range(FRAMES):
             g.compute_frame(stream.depth_mm[f], (W, H), k, 1, 1, icp_threshold, util.MU, f)
         poses, tracked, integrated = g.frame_log(FRAMES)
-        assert g.barrier_timeouts() == 0 and g.get_error() == 0
-        runs[name] = (poses.copy(), list(tracked), list(integrated), g.buffer("trackResult").copy(), g.icp_level_iterations(),
-                      g.buffer("volume").copy(), g.buffer("reduction").copy())
+        assert g.barrier_timeouts() == 0
+        runs[head] = (poses.copy(), list(tracked), list(integrated), g.buffer("trackResult").copy(), g.icp_level_iterations(),
+                      g.buffer("volume").copy())
         g.close()
     if icp_threshold == 0.0:
-        assert runs["slots"][4] == [10 * FRAMES, 5 * FRAMES, 4 * FRAMES]
-    else:
-        assert sum(runs["slots"][4]) < 12 * FRAMES                 # the levels do converge early on this stream
-    for name in ICP_SCHEDULES:
-        assert same_bits(runs["slots"][0], runs[name][0]), name
-        assert runs["slots"][1:3] == runs[name][1:3] and runs["slots"][4] == runs[name][4], name
-        assert np.array_equal(runs["slots"][3], runs[name][3]) and np.array_equal(runs["slots"][5], runs[name][5]), name
-        assert same_bits(runs["slots"][6], runs[name][6]), name
-
-
-def test_step_launch_schedule_through_the_phase_calls(hip, kfmod, stream, orc, monkeypatch):
-    """The same schedules behind kfh_tracking (phase API: no next frame riding along, verdict read back after every call) and
-    against the oracle's verdicts; a context whose loop is shorter than the default queue (-y 2,1) and one with a level of
-    zero iterations (-y 3,0,2: cpp:950-967 skips it)."""
-    k = list(stream.k)
-    for pyramid in ((10, 5, 4), (2, 1), (3, 0, 2)):
-        out = {}
-        for name in ("slots", "steps", "steps3"):
-            for var in ("KFH_ICP_GENERIC", "KFH_ICP_TAIL_HEAD", "KFH_ICP_STEPS"):
-                monkeypatch.delenv(var, raising=False)
-            for var, val in ICP_SCHEDULES[name].items():
-                monkeypatch.setenv(var, val)
-            g = kfmod.Kfusion((W, H), (64, 64, 64), util.VOL_DIM, stream.init_pos, pyramid)
-            verdicts = []
-            for f in range(FRAMES):
-                g.preprocessing(stream.depth_mm[f])
-                verdicts.append((g.tracking(k, util.ICP_THRESHOLD, 1, f), g.integration(k, 1, util.MU, f)))
-                g.raycasting(k, util.MU, f)
-            out[name] = (verdicts, g.get_pose(), g.buffer("volume").copy(), g.icp_level_iterations(), g.buffer("trackResult").copy())
-            g.close()
-        o = orc.OracleKfusion((W, H), (64, 64, 64), util.VOL_DIM, stream.init_pos, pyramid, omp=True)
-        ref = []
-        for f in range(FRAMES):
-            o.preprocessing(stream.depth_mm[f])
-            ref.append((o.tracking(k, util.ICP_THRESHOLD, 1, f), o.integration(k, 1, util.MU, f)))
-            o.raycasting(k, util.MU, f)
-        assert out["slots"][0] == ref, pyramid
-        assert np.abs(out["slots"][1] - o.get_pose()).max() <= 1e-4, pyramid
-        o.close()
-        for name in ("steps", "steps3"):
-            assert out[name][0] == out["slots"][0] and same_bits(out[name][1], out["slots"][1]), (pyramid, name)
-            assert np.array_equal(out[name][2], out["slots"][2]) and out[name][3] == out["slots"][3], (pyramid, name)
-            assert np.array_equal(out[name][4], out["slots"][4]), (pyramid, name)
+        assert runs["0"][4] == [10 * (FRAMES - 0), 5 * FRAMES, 4 * FRAMES]
+    for head in ("4", "1"):
+        assert same_bits(runs["0"][0], runs[head][0]), head
+        assert runs["0"][1:3] == runs[head][1:3] and runs["0"][4] == runs[head][4], head
+        assert np.array_equal(runs["0"][3], runs[head][3]) and np.array_equal(runs["0"][5], runs[head][5]), head
 
 
 def test_ray_march_variants_agree(hip, tmp_path):
@@ -274,8 +218,7 @@ def test_ray_march_variants_agree(hip, tmp_path):
                 {"KFH_RAY_GROUP": "4", "KFH_RAY_REORDER": "0"}, {"KFH_RAY_GROUP": "4", "KFH_EXACT_DIV": "0"},
                 {"KFH_RAY_GROUP": "4", "KFH_PIPELINE": "0"}, {"KFH_RAY_GROUP": "1"},
                 {"KFH_ICP_TAIL_HEAD": "0", "KFH_INTEGRATE_REORDER": "0"}, {"KFH_ICP_TAIL_CLOSES": "0", "KFH_SIDE_BIL_ITS": "0,1", "KFH_SIDE_PYR_ITS": "2"},
-                {"KFH_INTEGRATE_BATCH": "4", "KFH_INTEGRATE_CHUNKS": "16"}, {"KFH_INTEGRATE_BATCH": "16", "KFH_INTEGRATE_CHUNKS": "2"},
-                {"KFH_ICP_GENERIC": "0"}, {"KFH_ICP_STEPS": "5", "KFH_UPLOAD_WAIT": "device"})
+                {"KFH_INTEGRATE_BATCH": "4", "KFH_INTEGRATE_CHUNKS": "16"}, {"KFH_INTEGRATE_BATCH": "16", "KFH_INTEGRATE_CHUNKS": "2"})
     for i, env in enumerate(variants):
         out = str(tmp_path / ("v_%d.npz" % i))
         r = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
