@@ -205,3 +205,4 @@ def test_two_threads_each_with_a_context_and_synchronise_all(hip, kfmod):
         assert np.array_equal(vol, vol1) and same_bits(vertex, vertex1) and np.array_equal(img, img1)
         assert ctxs[i].get_error() == 0
         ctxs[i].close()
+
