@@ -487,6 +487,9 @@ __device__ __forceinline__ void halve(const float (&in)[2 * N], float (&out)[N],
 #ifndef KFH_REDUCE_SWAP
 #define KFH_REDUCE_SWAP 1
 #endif
+#if KFH_REDUCE_SWAP && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "halve_swap: v_permlane32_swap / v_permlane16_swap and the wait states written around them are gfx950's (build with -DKFH_REDUCE_SWAP=0 elsewhere)"
+#endif
 template <int N, int PARTNER>
 __device__ __forceinline__ void halve_swap(const float (&in)[2 * N], float (&out)[N]) {
     static_assert(PARTNER == 32 || PARTNER == 16, "row swaps");
@@ -537,6 +540,39 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__re
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) t += sm[w][threadIdx.x];
         partial[threadIdx.x] = t;
+    }
+}
+
+// Self-check of block_reduce_store (kfh_create runs it once per device): the row swaps and DPP adds above sit in inline assembly
+// whose wait states the compiler's hazard recogniser cannot see, and a wrong hazard would give wrong sums, not a fault.  Every lane
+// of a 1024-thread block gets 32 distinct pseudo-random values; the block's 32 sums must equal, BIT FOR BIT, the same fixed tree
+// evaluated with plain shuffles (halve<N> five times, lane ^ 1, then the waves in order).
+__global__ __launch_bounds__(1024) void k_verify_reduce(unsigned *mismatches, unsigned seed) {
+    __shared__ float ref_sm[1024 / 64][32];
+    __shared__ float got[32];
+    float acc[32], a16[16], a8[8], a4[4], a2[2], a1[1];
+    unsigned x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        x = x * 1664525u + 1013904223u;
+        acc[i] = (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;          // [-1, 1), 24 significant bits: the additions round
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    halve<16>(acc, a16, lane & 32, 32);
+    halve<8>(a16, a8, lane & 16, 16);
+    halve<4>(a8, a4, lane & 8, 8);
+    halve<2>(a4, a2, lane & 4, 4);
+    halve<1>(a2, a1, lane & 2, 2);
+    const float v = a1[0] + __shfl_xor(a1[0], 1, 64);
+    const int index = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) ref_sm[wave][index] = v;
+    block_reduce_store<1024>(acc, got);          // (ends with the 32 sums in `got`; its own barrier orders ref_sm as well)
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = ref_sm[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 1024 / 64; ++w) t += ref_sm[w][threadIdx.x];
+        if (__builtin_bit_cast(unsigned, t) != __builtin_bit_cast(unsigned, got[threadIdx.x])) atomicAdd(mismatches, 1u);
     }
 }
 
@@ -2473,6 +2509,27 @@ static bool fast_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStre
 }
 
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) { (void)fast_division(dim, sx, sy, sz, s); }
+
+// k_verify_reduce, once per device and process; false = the ICP block reduction does not compute its reference tree on this device
+bool reduction_verified(hipStream_t s) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, bool>> done;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &e : done) if (e.first == dev) return e.second;
+    bool ok = false;
+    unsigned *dm = nullptr;
+    if (hipMalloc(&dm, sizeof *dm) == hipSuccess) {
+        unsigned h = 1;
+        hipMemsetAsync(dm, 0, sizeof *dm, s);
+        k_verify_reduce<<<64, 1024, 0, s>>>(dm, 0x9E3779B9u); launched("k_verify_reduce");
+        if (hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) ok = h == 0;
+        hipFree(dm);
+    }
+    done.push_back(std::make_pair(dev, ok));
+    return ok;
+}
 // the bilateral filter's range divisor 2 e_d^2 (its numerators, squared depth differences, stay far below 2^24 for depth in metres)
 void prepare_bilateral_division(float e_d, hipStream_t s) { (void)verified_divisor(e_d * e_d * 2, s); }
 

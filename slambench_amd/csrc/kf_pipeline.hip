@@ -743,6 +743,12 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     kfh_reset(c);
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     launch::prepare_bilateral_division(e_delta, c->stream);
+    if (!launch::reduction_verified(c->stream)) {      // (fatal: every ICP sum of this backend goes through that reduction)
+        g_last_error = "kfh_create: the ICP block reduction failed its self-check on this device (k_verify_reduce)";
+        fprintf(stderr, "[kfusion-hip] %s\n", g_last_error.c_str());
+        kfh_destroy(c);
+        return nullptr;
+    }
     if (getenv("KERNEL_TIMINGS")) { c->kernel_timings = true; c->prof_mask = (1u << KFH_PROF_COUNT) - 1u; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     {

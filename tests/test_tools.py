@@ -223,11 +223,12 @@ def test_bench_timed_run_reports_a_failing_rank(capsys):
     def broken():
         raise RuntimeError("no device")
 
+    S = bench.Session(fake_torch, None, 1, 0, 0, "cpu", False)
     with pytest.raises(SystemExit):
-        bench.timed_run(broken, fake_torch, None, multi, 2, 3, 1, "cpu")
+        bench.timed_run(S, broken, multi, 2, 3, 1)
     assert "failed before the timed region" in capsys.readouterr().err
-    elapsed, leg, err = bench.timed_run(lambda: Leg(), fake_torch, None, multi, 2, 3, 1, "cpu")
+    elapsed, leg, err = bench.timed_run(S, lambda: Leg(), multi, 2, 3, 1)
     assert err is None and leg.steps == [0, 1, 2, 3, 4] and leg.syncs == 2 and elapsed >= 0
-    elapsed, leg, err = bench.timed_run(lambda: Leg(fail_at=3), fake_torch, None, multi, 2, 3, 1, "cpu")
+    elapsed, leg, err = bench.timed_run(S, lambda: Leg(fail_at=3), multi, 2, 3, 1)
     assert isinstance(err, RuntimeError) and leg.steps == [0, 1, 2]
     assert bench.icp_launches((10, 5, 4)) == 14 and bench.icp_launches((10, 5, 4, 4)) == 18
