@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   n_gpus / ranks_seen         the world size of the process group and an all-reduce of ones over it (RCCL saw that many ranks)
   configs                     compact legs of BASELINE configs[2] (cfg3) and configs[3] (cfg4) of the same run: value, ms_per_step,
                               value_host_input, roofline of integrate / raycast / the ICP loop with traffic and traffic_source
+  roofline*.traffic           HBM bytes per launch from rocprofv3 --pmc passes over child runs of this script (N = 1; else the committed file)
   roofline / roofline_other   icp loop, k_integrate, k_raycast: algorithmic bytes / HIP-event time measured in this run
   cpu_baseline                the OpenMP oracle timed on the host cores on a bounded prefix of the same stream
   fps_total                   the same queued loop plus the three renders and their read-back
@@ -91,6 +92,8 @@ def parse(argv=None):
                     help="comma list of configurations measured as compact legs after the headline and reported under \"configs\" "
                          "(default: cfg3,cfg4 when the headline is cfg2, else none; \"none\" = none)")
     ap.add_argument("--extra-steps", type=int, default=40, help="timed frames of a compact leg (warm-up: 8)")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="roofline.traffic from the committed profiles/traffic_<config>.json instead of two child runs under rocprofv3 --pmc (N = 1 only)")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="rehearsal of the N-rank plumbing without a GPU: rendezvous, barriers, all-reduces and the JSON line are real, "
                          "the frames are not run (value is null, \"dry_run\": true); used by tests/test_bench_ranks.py")
@@ -381,31 +384,82 @@ def main(argv=None):
             dist.destroy_process_group()
 
 
-def traffic_of(config):
-    """HBM bytes per launch from the PMC passes of profiles/collect_traffic.sh (rocprofv3 cannot wrap this process from inside): read
-    from the committed summary of this configuration, NOT measured in this run - `traffic_source` in the line says so."""
+def _traffic_from(tj):
+    traffic = {}
+    for kname, v in tj.items():
+        for short in ("integrate", "raycast"):
+            if ("k_" + short) in kname:
+                traffic[short] = v["hbm_bytes_per_launch"]
+    # the ICP loop of a frame = all k_icp* launches (+ k_control when it is a launch of its own); frames of the run =
+    # launches of k_raycast (one per frame)
+    frames_t = sum(v["launches"] for kname, v in tj.items() if "k_raycast" in kname)
+    loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
+    if frames_t and loop_t:
+        traffic["icp"] = round(loop_t / frames_t)
+    return traffic
+
+
+def measure_traffic(config, timeout_s=150):
+    """HBM bytes per launch measured NOW: rocprofv3 cannot attach to this process, so two child runs of this script (40 frames of the
+    same configuration) are profiled, FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes as MI355X_MICROARCH.md prescribes
+    (profiles/collect_traffic.sh does the same by hand), and summarised with its units and gfx950 corrections
+    (profiles/summarise_traffic.py).  Returns (traffic, source) or None if rocprofv3 is missing or a pass fails."""
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="kfh_traffic_")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            # (the program itself after `--`: the profiler's preloaded library initialises the GPU before the child starts)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-total",
+                   "--no-host-buffers", "--extra-configs", "none", "--no-measure-traffic"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                print("bench.py: traffic pass %s of %s failed (rc %d): %s" % (counter, config, r.returncode, r.stderr[-300:]), file=sys.stderr)
+                return None
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import summarise_traffic
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            summarise_traffic.main(tmp)
+        traffic = _traffic_from(json.load(open(os.path.join(tmp, "traffic.json"))))
+        if not traffic:
+            return None
+        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate child runs of bench.py --config %s --steps 40, "
+                         "KiB units, FETCH doubled for gfx950 as profiles/summarise_traffic.py documents)" % config)
+    except Exception as e:       # noqa: BLE001
+        print("bench.py: traffic measurement of %s failed: %r" % (config, e), file=sys.stderr)
+        return None
+    finally:
+        import shutil as _sh
+        _sh.rmtree(tmp, ignore_errors=True)
+
+
+def traffic_of(config, measure):
+    """HBM bytes per launch from the PMC counters: measured by child runs under rocprofv3 when asked (the default at N = 1), else - or if
+    that fails - read from the committed summary of this configuration; `traffic_source` in the line says which."""
+    if measure:
+        got = measure_traffic(config)
+        if got:
+            return got
     traffic, source = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
     if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        for kname, v in tj.items():
-            for short in ("integrate", "raycast"):
-                if ("k_" + short) in kname:
-                    traffic[short] = v["hbm_bytes_per_launch"]
-        # the ICP loop of a frame = all k_icp* launches (+ k_control when it is a launch of its own); frames of the run =
-        # launches of k_raycast (one per frame)
-        frames_t = sum(v["launches"] for kname, v in tj.items() if "k_raycast" in kname)
-        loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
-        if frames_t and loop_t:
-            traffic["icp"] = round(loop_t / frames_t)
+        traffic = _traffic_from(json.load(open(tpath)))
         source = "profiles/traffic_%s.json: committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, profiles/collect_traffic.sh) of the same command, not measured in this run" % config
     return traffic, source
 
 
-def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct):
+def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct, measure=False):
     """roofline entries of k_integrate, k_raycast and the ICP loop: algorithmic bytes / HIP-event time of this run"""
     W, H, vres, pyramid, irate, zrate = cfg
-    traffic, source = traffic_of(config_name)
+    traffic, source = traffic_of(config_name, measure)
     P = W * H
     roof = {}
     for name in ("integrate", "raycast"):
@@ -556,12 +610,12 @@ def measure(S, args, multi, config_name, steps, warmup, full):
         # runs just far enough to have a surface to cast at (6 frames) and counts on the two that follow
         _, v_distinct = cpu_baseline(wl, cfg, 0.0, min(n_frames + V_FRAMES, 6 + V_FRAMES), min_frames=6)
     host = None
+    d_depth = None                      # (the legs are over: the child processes below get the device to themselves)
+    torch.cuda.empty_cache()
     if full and not args.no_host_buffers and S.world == 1:
-        del d_depth
-        torch.cuda.empty_cache()
         host = host_buffers_leg(wl, cfg, n_frames)
-
-    roof = rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct)
+    roof = rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct,
+                     measure=S.world == 1 and not args.no_measure_traffic)
     res = {
         "workload": workload_string(config_name, cfg, wl),
         "value": round(total_frames / t_max, 2), "ms_per_step": round(t_max / (steps * spg) * 1e3, 4), "steps": steps, "warmup": warmup,
