@@ -232,3 +232,22 @@ def test_bench_timed_run_reports_a_failing_rank(capsys):
     elapsed, leg, err = bench.timed_run(S, lambda: Leg(fail_at=3), multi, 2, 3, 1)
     assert isinstance(err, RuntimeError) and leg.steps == [0, 1, 2]
     assert bench.icp_launches((10, 5, 4)) == 14 and bench.icp_launches((10, 5, 4, 4)) == 18
+
+
+def test_bench_traffic_falls_back_to_the_committed_summary(monkeypatch):
+    """roofline.traffic: measured by child runs under rocprofv3 when that works, else the committed profiles/traffic_<config>.json -
+    and `traffic_source` says which of the two it was."""
+    import bench
+    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=150: None)
+    traffic, source = bench.traffic_of("cfg2", True)
+    assert set(traffic) == {"integrate", "raycast", "icp"} and all(v > 1e6 for v in traffic.values())
+    assert "not measured in this run" in source and "profiles/traffic_cfg2.json" in source
+    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=150: ({"integrate": 1, "raycast": 2, "icp": 3}, "measured in this run: test"))
+    assert bench.traffic_of("cfg2", True) == ({"integrate": 1, "raycast": 2, "icp": 3}, "measured in this run: test")
+    assert "not measured" in bench.traffic_of("cfg2", False)[1]           # --no-measure-traffic / N > 1
+    # the ICP loop's figure: bytes of every k_icp* / k_control launch of the run over its frames (= launches of k_raycast)
+    sample = {"kf::k_raycast<4, 1>": {"launches": 10, "hbm_bytes_per_launch": 200, "hbm_bytes_total": 2000},
+              "kf::k_integrate<8, true>": {"launches": 5, "hbm_bytes_per_launch": 300, "hbm_bytes_total": 1500},
+              "kf::k_icp_iter": {"launches": 90, "hbm_bytes_per_launch": 50, "hbm_bytes_total": 4000},
+              "kf::k_icp_tail": {"launches": 10, "hbm_bytes_per_launch": 10, "hbm_bytes_total": 100}}
+    assert bench._traffic_from(sample) == {"raycast": 200, "integrate": 300, "icp": 410}
