@@ -93,8 +93,22 @@ def test_benchmark_cli_rejects_bad_flags():
     assert r.returncode == 1 and "No input found." in r.stderr
 
 
-def test_perfstats_summary_block():
-    """PerfStats::print_all_data's closing block (perfstats.h:330-343): mean, POPULATION standard deviation, min, max."""
+def test_perfstats_summary_block_equals_the_references_compiled_perfstats():
+    """SURVEY §8 f4.  tests/golden/perfstats_vectors.json is what the reference's thirdparty/perfstats.h, compiled where it lies with the
+    reference's -O3 (oracle/_ref/perfstats_probe, tests/golden/make_perfstats_vectors.py), prints as the closing block of
+    PerfStats::print_all_data for seeded tables of benchmark-log columns: in the form it takes when the log went to stdout (fixed
+    notation, left-aligned names) and when it went to a file (default notation, right-aligned).  The python twin must produce the same
+    characters - including the reference's divisor N + 1 under the "standard deviation"."""
+    import json
+    import os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "perfstats_vectors.json")))
+    assert set(vec["cases"]) == {"twelve_frames", "one_frame", "ninety_frames"}
+    for name, case in vec["cases"].items():
+        cols = {n: [float(r[i]) for r in case["rows"]] for i, n in enumerate(vec["columns"])}
+        st = perfstats.summarise_columns(cols)
+        assert perfstats.render(st, log_on_stdout=True).rstrip("\n").split("\n") == case["summary_log_on_stdout"], name
+        assert perfstats.render(st, log_on_stdout=False).rstrip("\n").split("\n") == case["summary_log_in_file"], name
+    # from a log as kfusion-benchmark-* writes it: every column of the header, frame included, in the header's order
     pos = np.zeros((4, 3))
     text = _fake_log(pos, [1, 1, 1, 1]).split("\n")
     rows = [r.split("\t") for r in text[1:5]]
@@ -102,11 +116,27 @@ def test_perfstats_summary_block():
         r[7] = "%.6f" % (0.001 * (i + 1))            # computation column: 1, 2, 3, 4 ms
     text = "\n".join([text[0]] + ["\t".join(r) for r in rows]) + "\n"
     st = perfstats.summary(text)
-    assert "frame" not in st and st["computation"]["n"] == 4
-    assert abs(st["computation"]["mean"] - 0.0025) < 1e-12 and abs(st["computation"]["sd"] - np.std([1e-3, 2e-3, 3e-3, 4e-3])) < 1e-12
-    assert st["computation"]["min"] == 0.001 and st["computation"]["max"] == 0.004
+    assert list(st)[:2] == ["frame", "acquisition"] and st["computation"]["n"] == 4
+    assert abs(st["computation"]["mean"] - 0.0025) < 1e-12
+    assert abs(st["computation"]["sd"] - np.sqrt(np.sum((np.array([1e-3, 2e-3, 3e-3, 4e-3]) - 0.0025) ** 2) / 5)) < 1e-15      # N + 1 = 5
     out = perfstats.render(st)
-    assert out.count("\n") == 13 and "#   computation\tMean:\t0.0025000000\tStandard deviation:\t" in out
+    assert out.count("\n") == 14 and "#   computation\tMean:\t0.0025\tStandard deviation:\t0.001\tmin:\t0.001\tmax:\t0.004" in out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "perfstats_probe")),
+                    reason="reference build absent (GPU box)")
+def test_perfstats_golden_file_is_what_the_reference_build_prints_today():
+    """Build container only: the committed fixture is not stale."""
+    import json
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    import make_perfstats_vectors as mk
+    vec = json.load(open(os.path.join(golden, "perfstats_vectors.json")))
+    probe = os.path.join(os.path.dirname(golden), "..", "oracle", "_ref", "perfstats_probe")
+    for name, case in vec["cases"].items():
+        assert mk.run(probe, case["rows"], False) == case["summary_log_on_stdout"], name
+        assert mk.run(probe, case["rows"], True) == case["summary_log_in_file"], name
 
 
 def test_rocprof_trace_to_kernel_log():
