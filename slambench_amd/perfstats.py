@@ -4,7 +4,7 @@ loop of ``PerfStats::print_all_data``, called by mainQt.cpp:176 / SlamBenchQt.cp
     # <name>\tMean:\t<mean>\tStandard deviation:\t<sd>\tmin:\t<min>\tmax:\t<max>
 
 Held to the reference's own compiled code: ``tests/golden/perfstats_vectors.json`` is what that header, compiled where it lies with
-the reference's ``-O3`` (``oracle/_ref/perfstats_probe``), prints for seeded sample tables; this module reproduces it character for
+the reference's ``-O3`` (the probe of ``tests/golden/make_perfstats_vectors.py``), prints for seeded sample tables; this module reproduces it character for
 character.  Three things the header does that a reading of it would not suggest:
 
 * the block always goes to ``std::cout``.  When the log itself went to stdout too, that stream has been switched to fixed notation
