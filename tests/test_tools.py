@@ -268,11 +268,11 @@ def test_bench_traffic_falls_back_to_the_committed_summary(monkeypatch):
     """roofline.traffic: measured by child runs under rocprofv3 when that works, else the committed profiles/traffic_<config>.json -
     and `traffic_source` says which of the two it was."""
     import bench
-    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=150: None)
+    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=90: None)
     traffic, source = bench.traffic_of("cfg2", True)
     assert set(traffic) == {"integrate", "raycast", "icp"} and all(v > 1e6 for v in traffic.values())
     assert "not measured in this run" in source and "profiles/traffic_cfg2.json" in source
-    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=150: ({"integrate": 1, "raycast": 2, "icp": 3}, "measured in this run: test"))
+    monkeypatch.setattr(bench, "measure_traffic", lambda config, timeout_s=90: ({"integrate": 1, "raycast": 2, "icp": 3}, "measured in this run: test"))
     assert bench.traffic_of("cfg2", True) == ({"integrate": 1, "raycast": 2, "icp": 3}, "measured in this run: test")
     assert "not measured" in bench.traffic_of("cfg2", False)[1]           # --no-measure-traffic / N > 1
     # the ICP loop's figure: bytes of every k_icp* / k_control launch of the run over its frames (= launches of k_raycast)
