@@ -558,6 +558,14 @@ def measure(S, args, multi, config_name, steps, warmup, full):
         j = multi.aggregate(multi.RankStats(steps, e, failed=0 if err is None else 1), dist, device=S.coll_device)
         return (None, "%d rank(s) failed%s" % (j.failed, ": %r" % (err,) if err is not None else "")) if j.failed else (j.fps, None)
 
+    # A throw-away leg first: the very first leg of a process starts from an idle-clocked GPU and came out 15-25 % low for it
+    # (fps_total 2400-2560 as the first leg against 2990-3200 otherwise, profiles/r03_render_async_ab.txt).  Not timed, not reported.
+    if full and not S.dry:
+        _, pre, perr = timed_run(S, lambda: mk(False), multi, min(warmup, 8), min(60, steps), 0)
+        if pre is not None:
+            pre.close()
+        if perr is not None:
+            print("bench.py: rank %d: the pre-heating leg failed: %r" % (S.rank, perr), file=sys.stderr)
     # The secondary legs run FIRST: each is a measurement of its own and leaves the device at its working clocks for the headline
     # leg, which otherwise starts from an idle-clocked GPU and, at the 25 frames of a `--steps 20 --warmup 5` run, ends before the
     # clocks have settled.
