@@ -94,6 +94,9 @@ def parse(argv=None):
     ap.add_argument("--extra-steps", type=int, default=40, help="timed frames of a compact leg (warm-up: 8)")
     ap.add_argument("--no-measure-traffic", action="store_true",
                     help="roofline.traffic from the committed profiles/traffic_<config>.json instead of two child runs under rocprofv3 --pmc (N = 1 only)")
+    ap.add_argument("--no-preheat", action="store_true",
+                    help="skip the throw-away leg that brings the GPU to its working clocks (the profiled child runs of the traffic measurement: "
+                         "one context, so that every launch of the trace belongs to the 'steps + warmup' frames)")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="rehearsal of the N-rank plumbing without a GPU: rendezvous, barriers, all-reduces and the JSON line are real, "
                          "the frames are not run (value is null, \"dry_run\": true); used by tests/test_bench_ranks.py")
@@ -103,13 +106,10 @@ def parse(argv=None):
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` launched plainly: start the N ranks as a CHILD `torch.distributed.run` and relay its output and exit
     code.  Called before anything in this process has touched torch or the GPU (a process that has must never exec another)."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torchrun starts its own rendezvous store on a free port of 127.0.0.1 and hands it to the ranks - no port is
+    # picked here (a bind(0)-close-reuse sequence can lose the port to another process in between)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + list(argv)
     print("bench.py: --gpus %d without a torch.distributed environment: starting %d ranks: %s" % (args.gpus, args.gpus, " ".join(cmd)), file=sys.stderr)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -384,19 +384,37 @@ def main(argv=None):
             dist.destroy_process_group()
 
 
-def _traffic_from(tj):
+def _traffic_from(tj, frames=None):
+    """{integrate, raycast, icp: HBM bytes per launch} from a summary of profiles/summarise_traffic.py.  `frames`: frames of the profiled
+    run (steps + warmup of its ONE context); None for a summary that does not say - then the launches of k_raycast stand in, which is a
+    few per cent high (frames 0-2 of a context cast no rays)."""
     traffic = {}
     for kname, v in tj.items():
+        if not isinstance(v, dict):
+            continue
         for short in ("integrate", "raycast"):
             if ("k_" + short) in kname:
                 traffic[short] = v["hbm_bytes_per_launch"]
-    # the ICP loop of a frame = all k_icp* launches (+ k_control when it is a launch of its own); frames of the run =
-    # launches of k_raycast (one per frame)
-    frames_t = sum(v["launches"] for kname, v in tj.items() if "k_raycast" in kname)
-    loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in tj.items() if "k_icp" in kname or "k_control" in kname)
+    # the ICP loop of a frame = all k_icp* launches (+ k_control when it is a launch of its own)
+    kernels = {k: v for k, v in tj.items() if isinstance(v, dict)}
+    frames_t = frames or tj.get("frames") or sum(v["launches"] for kname, v in kernels.items() if "k_raycast" in kname)
+    loop_t = sum(v.get("hbm_bytes_total", 0) for kname, v in kernels.items() if "k_icp" in kname or "k_control" in kname)
     if frames_t and loop_t:
         traffic["icp"] = round(loop_t / frames_t)
     return traffic
+
+
+def profiler_in_environment(environ=None):
+    """True when this process itself runs under rocprofv3 (its preload / tool variables are inherited): a profiled child started from
+    here would be nested profiling, and its launcher hops (env -> python3 -> the program) would each load the profiler's preloaded
+    library - which initialises the GPU - and then exec the next program."""
+    environ = os.environ if environ is None else environ
+    if any(k in environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) or any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in environ):
+        return True
+    return any(("rocprof" in v) or ("rocprofiler" in v) for v in (environ.get("LD_PRELOAD", ""),))
+
+
+TRAFFIC_STEPS, TRAFFIC_WARMUP = 40, 10
 
 
 _TRAFFIC_MEASURABLE = [True]      # cleared by the first pass that fails: the remaining configurations then use the committed summaries
@@ -411,17 +429,22 @@ def measure_traffic(config, timeout_s=90):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not _TRAFFIC_MEASURABLE[0] or not os.path.exists(exe):
         return None
+    if profiler_in_environment():
+        print("bench.py: running under a profiler: roofline.traffic comes from the committed summary (no nested rocprofv3 runs)", file=sys.stderr)
+        return None
     _TRAFFIC_MEASURABLE[0] = False      # (until this configuration's two passes have gone through)
     tmp = tempfile.mkdtemp(prefix="kfh_traffic_")
     try:
-        env = dict(os.environ, TMPDIR="/tmp")
-        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-            env.pop(k, None)
+        # (no profiler variable can be in this environment - checked above -, so only the rank variables are taken out)
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["TMPDIR"] = "/tmp"
         for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-            # (the program itself after `--`: the profiler's preloaded library initialises the GPU before the child starts)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-total",
-                   "--no-host-buffers", "--extra-configs", "none", "--no-measure-traffic"]
+            # rocprofv3 is a python script: started with this interpreter (no `env` hop), and the program itself after `--`: the
+            # profiler's preloaded library initialises the GPU before the child starts.  The child runs ONE context (--no-preheat) and
+            # no profiled children of its own (--no-measure-traffic).
+            cmd = [sys.executable, exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, sub), "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--config", config, "--steps", str(TRAFFIC_STEPS), "--warmup", str(TRAFFIC_WARMUP), "--no-cpu-baseline",
+                   "--no-total", "--no-host-buffers", "--extra-configs", "none", "--no-measure-traffic", "--no-preheat"]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
             if r.returncode != 0:
                 print("bench.py: traffic pass %s of %s failed (rc %d): %s" % (counter, config, r.returncode, r.stderr[-300:]), file=sys.stderr)
@@ -432,11 +455,11 @@ def measure_traffic(config, timeout_s=90):
         import io
         with contextlib.redirect_stdout(io.StringIO()):
             summarise_traffic.main(tmp)
-        traffic = _traffic_from(json.load(open(os.path.join(tmp, "traffic.json"))))
+        traffic = _traffic_from(json.load(open(os.path.join(tmp, "traffic.json"))), frames=TRAFFIC_STEPS + TRAFFIC_WARMUP)
         if not traffic:
             return None
         _TRAFFIC_MEASURABLE[0] = True
-        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate child runs of bench.py --config %s --steps 40, "
+        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate child runs of bench.py --config %s --steps 40 --warmup 10, one context, "
                          "KiB units, FETCH doubled for gfx950 as profiles/summarise_traffic.py documents)" % config)
     except Exception as e:       # noqa: BLE001
         print("bench.py: traffic measurement of %s failed: %r" % (config, e), file=sys.stderr)
@@ -560,7 +583,7 @@ def measure(S, args, multi, config_name, steps, warmup, full):
 
     # A throw-away leg first: the very first leg of a process starts from an idle-clocked GPU and came out 15-25 % low for it
     # (fps_total 2400-2560 as the first leg against 2990-3200 otherwise, profiles/r03_render_async_ab.txt).  Not timed, not reported.
-    if full and not S.dry:
+    if full and not S.dry and not args.no_preheat:
         _, pre, perr = timed_run(S, lambda: mk(False), multi, min(warmup, 8), min(60, steps), 0)
         if pre is not None:
             pre.close()

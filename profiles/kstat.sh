@@ -7,7 +7,7 @@ i=0
 for envs in "$@"; do
   i=$((i+1))
   out=/tmp/kstat_$$_$i
-  env $envs rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --config $cfg --steps 120 --warmup 20 --no-cpu-baseline --no-total --no-host-buffers --profile-every 0 > $out.json 2> $out.err
+  env $envs rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --no-measure-traffic --extra-configs none --config $cfg --steps 120 --warmup 20 --no-cpu-baseline --no-total --no-host-buffers --profile-every 0 > $out.json 2> $out.err
   python3 - $out "$envs" $out.json <<'PY'
 import csv, glob, json, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]

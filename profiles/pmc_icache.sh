@@ -3,7 +3,7 @@
 out=$1; shift
 export TMPDIR=/tmp
 mkdir -p "$out"
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$out" -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-total > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$out" -- python3 bench.py --no-measure-traffic --extra-configs none --steps 40 --warmup 10 --no-cpu-baseline --no-total > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
 python3 - "$out" <<'PY'
 import csv, collections, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_counter_collection.csv")[0]

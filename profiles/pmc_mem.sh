@@ -12,7 +12,7 @@ for set in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_GATE_EN1_sum"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/p$i" -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers $BENCH_ARGS > "$out/p$i.json" 2> "$out/p$i.err" || { echo "pass $i failed"; tail -3 "$out/p$i.err" | cut -c1-200; }
+  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/p$i" -- python3 bench.py --no-measure-traffic --extra-configs none --steps 30 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers $BENCH_ARGS > "$out/p$i.json" 2> "$out/p$i.err" || { echo "pass $i failed"; tail -3 "$out/p$i.err" | cut -c1-200; }
   echo "pass $i done"
 done
 python3 - "$out" <<'PY'

@@ -3,7 +3,7 @@
 out=$1; shift
 export TMPDIR=/tmp
 mkdir -p "$out"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$out" -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers $BENCH_ARGS > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$out" -- python3 bench.py --no-measure-traffic --extra-configs none --steps 40 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers $BENCH_ARGS > "$out/bench.json" 2> "$out/bench.err"
 python3 - "$out" <<'PY'
 import csv, collections, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_counter_collection.csv")[0]

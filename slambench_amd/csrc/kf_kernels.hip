@@ -545,10 +545,12 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__re
 
 // Self-check of block_reduce_store (kfh_create runs it once per device): the row swaps and DPP adds above sit in inline assembly
 // whose wait states the compiler's hazard recogniser cannot see, and a wrong hazard would give wrong sums, not a fault.  Every lane
-// of a 1024-thread block gets 32 distinct pseudo-random values; the block's 32 sums must equal, BIT FOR BIT, the same fixed tree
-// evaluated with plain shuffles (halve<N> five times, lane ^ 1, then the waves in order).
-__global__ __launch_bounds__(1024) void k_verify_reduce(unsigned *mismatches, unsigned seed) {
-    __shared__ float ref_sm[1024 / 64][32];
+// of a block gets 32 distinct pseudo-random values; the block's 32 sums must equal, BIT FOR BIT, the same fixed tree
+// evaluated with plain shuffles (halve<N> five times, lane ^ 1, then the waves in order).  Run for both instantiations the
+// backend launches: ICP_THREADS (the fused ICP kernels) and TR_THREADS (k_track_reduce / k_reduce_trackdata).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_verify_reduce(unsigned *mismatches, unsigned seed) {
+    __shared__ float ref_sm[NT / 64][32];
     __shared__ float got[32];
     float acc[32], a16[16], a8[8], a4[4], a2[2], a1[1];
     unsigned x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
@@ -566,12 +568,12 @@ __global__ __launch_bounds__(1024) void k_verify_reduce(unsigned *mismatches, un
     const float v = a1[0] + __shfl_xor(a1[0], 1, 64);
     const int index = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     if ((lane & 1) == 0) ref_sm[wave][index] = v;
-    block_reduce_store<1024>(acc, got);          // (ends with the 32 sums in `got`; its own barrier orders ref_sm as well)
+    block_reduce_store<NT>(acc, got);            // (ends with the 32 sums in `got`; its own barrier orders ref_sm as well)
     __syncthreads();
     if (threadIdx.x < 32) {
         float t = ref_sm[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < 1024 / 64; ++w) t += ref_sm[w][threadIdx.x];
+        for (int w = 1; w < NT / 64; ++w) t += ref_sm[w][threadIdx.x];
         if (__builtin_bit_cast(unsigned, t) != __builtin_bit_cast(unsigned, got[threadIdx.x])) atomicAdd(mismatches, 1u);
     }
 }
@@ -2510,25 +2512,34 @@ static bool fast_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStre
 
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) { (void)fast_division(dim, sx, sy, sz, s); }
 
-// k_verify_reduce, once per device and process; false = the ICP block reduction does not compute its reference tree on this device
-bool reduction_verified(hipStream_t s) {
+// k_verify_reduce, once per device and process: 1 = the ICP block reduction computes its reference tree on this device (both
+// instantiations the backend launches), 0 = it does not (a completed comparison found a mismatch), -1 = the check could not be run
+// (allocation, launch, copy or wait failed: a runtime error, reported as such and NOT remembered - the next kfh_create tries again).
+int reduction_verified(hipStream_t s) {
     static std::mutex mu;
     static std::vector<std::pair<int, bool>> done;
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    for (const auto &e : done) if (e.first == dev) return e.second;
-    bool ok = false;
+    for (const auto &e : done) if (e.first == dev) return e.second ? 1 : 0;
     unsigned *dm = nullptr;
-    if (hipMalloc(&dm, sizeof *dm) == hipSuccess) {
-        unsigned h = 1;
-        hipMemsetAsync(dm, 0, sizeof *dm, s);
-        k_verify_reduce<<<64, 1024, 0, s>>>(dm, 0x9E3779B9u); launched("k_verify_reduce");
-        if (hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) ok = h == 0;
-        hipFree(dm);
+    if (hipMalloc(&dm, sizeof *dm) != hipSuccess) return -1;
+    unsigned h = 1;
+    bool ran = hipMemsetAsync(dm, 0, sizeof *dm, s) == hipSuccess;
+    if (ran) {
+        k_verify_reduce<1024><<<64, 1024, 0, s>>>(dm, 0x9E3779B9u);
+        ran = hipGetLastError() == hipSuccess;           // (examined here, not booked to a context: a rejected launch verifies nothing)
     }
-    done.push_back(std::make_pair(dev, ok));
-    return ok;
+    if (ran) {
+        static_assert(ICP_THREADS == 1024, "k_verify_reduce<1024> stands for the ICP kernels' instantiation");
+        k_verify_reduce<TR_THREADS><<<64, TR_THREADS, 0, s>>>(dm, 0x7F4A7C15u);
+        ran = hipGetLastError() == hipSuccess;
+    }
+    ran = ran && hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    hipFree(dm);
+    if (!ran) return -1;
+    done.push_back(std::make_pair(dev, h == 0));
+    return h == 0 ? 1 : 0;
 }
 // the bilateral filter's range divisor 2 e_d^2 (its numerators, squared depth differences, stay far below 2^24 for depth in metres)
 void prepare_bilateral_division(float e_d, hipStream_t s) { (void)verified_divisor(e_d * e_d * 2, s); }

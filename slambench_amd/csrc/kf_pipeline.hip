@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct kfh_context {
     unsigned seen_failed_frames = 0;
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
+    bool barrier_slot = false;         // holds one of the device's eight k_icp_tail slots (create_common; returned by kfh_destroy)
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
@@ -135,6 +137,7 @@ struct kfh_context {
 // backends keep file-scope state, so kfh_synchronise_all() waits for all of them
 static std::mutex g_registry_mu;
 static std::vector<kfh_context *> g_registry;
+static std::map<int, int> g_barrier_slots;   // per device: contexts holding one of the eight co-residency slots of k_icp_tail (guarded by g_registry_mu)
 
 static hipEvent_t prof_event(kfh_context *c, int phase) {
     std::vector<hipEvent_t> &v = c->prof_events[phase];
@@ -704,10 +707,12 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
         // k_icp_tail synchronises its <= 32 workgroups (one CU each) with a grid barrier: they must be resident together.  Eight
         // such launches fit the 256 CUs at once whatever else runs, so up to eight contexts per device may use it; a ninth
         // gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could time out.
+        // The slot is RESERVED here, under the registry lock (the context itself joins the registry only when it is complete): two
+        // threads creating contexts at once cannot both take the eighth.  kfh_destroy gives it back, also for a creation that fails.
         std::lock_guard<std::mutex> lk(g_registry_mu);
-        int live = 0;
-        for (const kfh_context *o : g_registry) live += o->device == c->device ? 1 : 0;
-        if (live >= 8) c->icp_tail_head.assign(1, 0);
+        int &taken = g_barrier_slots[c->device];
+        if (taken >= 8) c->icp_tail_head.assign(1, 0);
+        else { ++taken; c->barrier_slot = true; }
     }
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
@@ -743,8 +748,9 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     kfh_reset(c);
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     launch::prepare_bilateral_division(e_delta, c->stream);
-    if (!launch::reduction_verified(c->stream)) {      // (fatal: every ICP sum of this backend goes through that reduction)
-        g_last_error = "kfh_create: the ICP block reduction failed its self-check on this device (k_verify_reduce)";
+    if (const int verdict = launch::reduction_verified(c->stream); verdict != 1) {      // (fatal: every ICP sum of this backend goes through that reduction)
+        g_last_error = verdict == 0 ? "kfh_create: the ICP block reduction failed its self-check on this device (k_verify_reduce)"
+                                    : "kfh_create: the self-check of the ICP block reduction could not be run (HIP error: allocation, launch or wait)";
         fprintf(stderr, "[kfusion-hip] %s\n", g_last_error.c_str());
         kfh_destroy(c);
         return nullptr;
@@ -794,6 +800,7 @@ void kfh_destroy(kfh_context *c) {
         std::lock_guard<std::mutex> lk(g_registry_mu);
         for (size_t i = 0; i < g_registry.size(); ++i)
             if (g_registry[i] == c) { g_registry.erase(g_registry.begin() + i); break; }
+        if (c->barrier_slot) { --g_barrier_slots[c->device]; c->barrier_slot = false; }
     }
     hipSetDevice(c->device);
     c->pend.valid = false;   // a frame still deferred is dropped with the context

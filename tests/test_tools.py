@@ -281,3 +281,30 @@ def test_bench_traffic_falls_back_to_the_committed_summary(monkeypatch):
               "kf::k_icp_iter": {"launches": 90, "hbm_bytes_per_launch": 50, "hbm_bytes_total": 4000},
               "kf::k_icp_tail": {"launches": 10, "hbm_bytes_per_launch": 10, "hbm_bytes_total": 100}}
     assert bench._traffic_from(sample) == {"raycast": 200, "integrate": 300, "icp": 410}
+    # with the frames of the profiled run known (steps + warmup of its one context) they are the divisor: frames 0-2 cast no rays
+    assert bench._traffic_from(sample, frames=13)["icp"] == round(4100 / 13)
+    assert bench._traffic_from(dict(sample, frames=20))["icp"] == 205
+
+
+def test_bench_never_profiles_a_child_from_a_profiled_process(monkeypatch):
+    """Under rocprofv3 (its preload / tool variables inherited) bench.py must not start profiled children of its own: nested
+    profiling, and every launcher hop of the child would load the preloaded library - which initialises the GPU - and exec the next
+    program.  measure_traffic() then returns None without spawning anything and the committed summary is used."""
+    import subprocess
+    import bench
+    spawned = []
+    monkeypatch.setattr(subprocess, "run", lambda *a, **kw: spawned.append(a) or (_ for _ in ()).throw(AssertionError("spawned a child")))
+    monkeypatch.setattr(bench, "_TRAFFIC_MEASURABLE", [True])
+    clean = {k: v for k, v in __import__("os").environ.items() if not bench.profiler_in_environment({k: v})}
+    assert not bench.profiler_in_environment(clean)
+    for var, val in (("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"), ("ROCPROF_COUNTERS", "pmc: FETCH_SIZE"),
+                     ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk.so"), ("ROCPROFILER_LIBRARY_CTOR", "1")):
+        assert bench.profiler_in_environment(dict(clean, **{var: val})), var
+        monkeypatch.setenv(var, val)
+        assert bench.measure_traffic("cfg2") is None
+        traffic, source = bench.traffic_of("cfg2", True)
+        assert "not measured in this run" in source and traffic
+        monkeypatch.delenv(var)
+    assert not spawned
+    assert bench._TRAFFIC_MEASURABLE == [True]          # refusing is not a failed pass: later configurations are not disabled by it
+    assert not bench.profiler_in_environment(dict(clean, LD_PRELOAD="/usr/lib/libfoo.so"))
