@@ -179,6 +179,8 @@ size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz);
 // verifies once per device and divisor (a few ms, synchronises the stream) the reciprocal form of pos*size/dim of the ray march
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void prepare_bilateral_division(float e_d, hipStream_t s);
+// verifies once per device and threshold (~1 ms, synchronises the stream) that length > t may be decided on the squared length (sqrt_gt_bound)
+void prepare_sqrt_bound(float t, hipStream_t s);
 // one-off self-check of the ICP block reduction's inline-assembly lane exchanges against the same tree written with plain shuffles:
 // 1 verified, 0 mismatch (remembered per device), -1 the check itself could not run (a HIP error; not remembered)
 int reduction_verified(hipStream_t s);

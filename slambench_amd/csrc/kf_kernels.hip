@@ -634,14 +634,24 @@ __global__ __launch_bounds__(TR_THREADS) void k_reduce_trackdata(float *__restri
 // One block; the pose never leaves HBM between ICP iterations.
 // =====================================================================================
 // `ws`: 72 doubles of LDS for the Jacobi fallback (see solve6_ws)
-__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold, bool &fast, double *ws) {
+__device__ __forceinline__ bool apply_update(M4 &pose, const float *red, float icp_threshold, bool &fast, double *ws,
+                                             unsigned long long *tr = nullptr) {
     double x[6];
-    fast = solve6_ldlt(red + 1, x);
+    KF_SOLVE_STAMP(tr, 8, red[1]);
+    fast = solve6_ldlt(red + 1, x, tr);
     if (!fast) solve6_ws(red + 1, x, reinterpret_cast<double (*)[6]>(ws), reinterpret_cast<double (*)[6]>(ws + 36));
-    const M4 delta = se3_exp_to_m4(x);
+    KF_SOLVE_STAMP(tr, 11, (float)(x[0] + x[5]));
+    const M4 delta = se3_exp_to_m4(x);       // (last row 0, 0, 0, 1 by construction)
+    KF_SOLVE_STAMP(tr, 12, delta.m[0][0] + delta.m[2][3] + delta.m[1][2]);
+#if KFH_SOLVE_LEAN
+    pose = last_row_is_rigid(pose) ? matmul_rigid(delta, pose) : matmul(delta, pose);
+#else
     pose = matmul(delta, pose);
+#endif
+    KF_SOLVE_STAMP(tr, 13, pose.m[2][3] + pose.m[0][0] + pose.m[1][1]);
     double n2 = 0.0;
     for (int i = 0; i < 6; ++i) n2 += x[i] * x[i];
+    KF_SOLVE_STAMP(tr, 14, (float)n2);
     // norm(x) < icp_threshold (cpp:772), compared as squares: no square root on this serial path
     return icp_threshold > 0.f && n2 < (double)icp_threshold * (double)icp_threshold;
 }
@@ -883,9 +893,10 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
     if (threadIdx.x == 0) {
         M4 pose = sh.pose;
         bool fast = true;
-        const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast, sh.jacobi_ws);   // < 0: timing probe
+        const bool converged = (icp_threshold < 0.f) ? false : apply_update(pose, sh.red, icp_threshold, fast, sh.jacobi_ws, blockIdx.x == 0 ? trace : nullptr);   // < 0: timing probe
         sh.pose = pose;
         if (converged) sh.done[prev_level] = 1;
+        KF_SOLVE_STAMP(blockIdx.x == 0 ? trace : nullptr, 15, sh.pose.m[0][0]);
         if (writer) {   // counters: atomics without a return value, so that this thread does not wait for the round trips
             atomicAdd(&st->icp_iterations, 1ull);
             atomicAdd(&st->icp_level_iterations[prev_level], 1ull);
@@ -1002,6 +1013,8 @@ struct IcpIterArgs {
     const float4 *refV, *refN;
     unsigned refW, refH;
     float icp_threshold, dist_threshold, normal_threshold;
+    float dist2_max;                      // >= 0: sqrtf(d) > dist_threshold <=> d > dist2_max for every float d (sqrt_gt_bound, verified on this device); < 0: take the square root
+    float inv_inW;                        // RN(1 / inW), used for p / inW while inW * inH <= 2^22 (0 = integer division)
     unsigned long long *trace;            // debugging (KFH_ICP_TRACE): stamps of block 0 / thread 0, else nullptr
     unsigned *ray_order, *ray_cost;       // side block `nblocks` of a plain launch: raycast dispatch order (nullptr = none)
     unsigned ray_tiles_x, ray_tiles_y, order_mode;
@@ -1027,6 +1040,52 @@ __device__ __forceinline__ bool icp_enter(IcpShared &sh, const IcpIterArgs &a, i
     return sh.executed != 0;
 }
 
+// trackKernel for one pixel (cpp:507-557) with the reduction's accumulation (cpp:297-356) inside the inlier branch: the operations, their
+// order and hence the bits are those of track_fetched() + accumulate(), but nothing is carried across the early exits except the
+// result code - as a PixelTrack handed from one routine to the other, every exit zeroed the seven error / Jacobian registers again
+// (~45 of the ~230 vector instructions per pixel of a kernel that is bound by instruction issue).  The two gathers from the reference
+// maps are issued together (the compiler otherwise sinks the vertex and the normal's y / z behind the tests that need them: three
+// dependent round trips); length(diff) > dist_threshold is decided on the squared length where sqrt_gt_bound() applies.
+#ifndef KFH_ICP_LEAN
+#define KFH_ICP_LEAN 1
+#endif
+struct AssocConsts { M4 T, view; int have_reference; unsigned refW; float wm1, hm1, dist_threshold, dist2_max, normal_threshold; };
+
+__device__ __forceinline__ int associate_accumulate(float (&acc)[32], float4 n4, float4 v4, const float4 *__restrict__ refV,
+                                                    const float4 *__restrict__ refN, const AssocConsts &C) {
+    if (n4.x == kInvalid) return -1;
+    const f3 pv = xform(C.T, mk3(v4.x, v4.y, v4.z));
+    unsigned ref = 0;
+    if (C.have_reference) {
+        const f3 pp = xform(C.view, pv);
+        const float u = pp.x / pp.z + 0.5f, w = pp.y / pp.z + 0.5f;
+        if (u < 0 || u > C.wm1 || w < 0 || w > C.hm1) return -2;
+        ref = (unsigned)u + (unsigned)w * C.refW;
+    }
+    float4 rn4 = refN[ref];
+    float4 rv4 = refV[ref];
+    asm volatile("" : "+v"(rn4.x), "+v"(rn4.y), "+v"(rn4.z), "+v"(rv4.x), "+v"(rv4.y), "+v"(rv4.z));   // both gathers requested here, whole
+    if (rn4.x == kInvalid) return -3;
+    const f3 n_ref = mk3(rn4.x, rn4.y, rn4.z);
+    const f3 diff = sub3(mk3(rv4.x, rv4.y, rv4.z), pv);
+    const float d2 = dot3(diff, diff);
+    if (C.dist2_max >= 0.f ? d2 > C.dist2_max : sqrtf(d2) > C.dist_threshold) return -4;     // (uniform choice)
+    const f3 pn = rotate(C.T, mk3(n4.x, n4.y, n4.z));
+    if (dot3(pn, n_ref) < C.normal_threshold) return -5;
+    const float e = dot3(n_ref, diff);
+    const f3 c = cross3(pv, n_ref);
+    const float J[6] = {n_ref.x, n_ref.y, n_ref.z, c.x, c.y, c.z};
+    acc[0] += e * e;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[1 + i] += e * J[i];
+    int k = 7;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int q = r; q < 6; ++q) acc[k++] += J[r] * J[q];
+    return 1;
+}
+
 // association + partial sums of ICP block `vb` (of a.nblocks) with the pose in sh
 __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs &a, unsigned vb, float *partials_out) {
     DevState *__restrict__ st = a.st;
@@ -1040,6 +1099,35 @@ __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs
     const unsigned n = a.inW * a.inH;
     const float4 *__restrict__ inV = a.inV, *__restrict__ inN = a.inN, *__restrict__ refV = a.refV, *__restrict__ refN = a.refN;
     int *__restrict__ result_map = a.result_map;
+#if KFH_ICP_LEAN
+    AssocConsts C;
+    C.T = T; C.view = view; C.have_reference = have_reference; C.refW = a.refW;
+    C.wm1 = (float)(a.refW - 1); C.hm1 = (float)(a.refH - 1);                // (the reference compares with the unsigned size - 1, cpp:527)
+    C.dist_threshold = a.dist_threshold; C.dist2_max = a.dist2_max; C.normal_threshold = a.normal_threshold;
+    // The four counters of the row ([28] inliers, [29] #(-4), [30] #(-5), [31] #(-1..-3)) are small integers, exact in float
+    // whatever the order of the additions: counted per WAVE on the scalar unit (ballot + bit count) and handed to lane 0 below,
+    // instead of three or four vector instructions per pixel and lane.
+    unsigned cnt_in = 0, cnt_dist = 0, cnt_norm = 0, cnt_other = 0;
+    const unsigned row_gap = a.refW - a.inW;     // the result map keeps the full-resolution row stride on every level (cpp:512)
+    for (unsigned p = vb * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
+        // the input maps are dense (row stride inW): pixel (px, py) is element p
+        float4 n4 = inN[p];
+        float4 v4 = inV[p];
+        asm volatile("" : "+v"(n4.x), "+v"(n4.y), "+v"(n4.z), "+v"(v4.x), "+v"(v4.y), "+v"(v4.z));   // one round trip for both maps
+        const int result = associate_accumulate(acc, n4, v4, refV, refN, C);
+        unsigned o = p;
+        if (row_gap) {      // (uniform) coarse level: p + py * (refW - inW); py = p / inW by a multiplication while that is exact
+            const unsigned py = a.inv_inW > 0.f ? (unsigned)(((float)p + 0.5f) * a.inv_inW) : p / a.inW;
+            o = p + __umul24(py, row_gap);
+        }
+        result_map[o] = result;
+        cnt_in += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result == 1));
+        cnt_dist += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result == -4));
+        cnt_norm += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result == -5));
+        cnt_other += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result < 0 && result > -4));
+    }
+    if ((threadIdx.x & 63) == 0) { acc[28] = (float)cnt_in; acc[29] = (float)cnt_dist; acc[30] = (float)cnt_norm; acc[31] = (float)cnt_other; }
+#else
     for (unsigned p = vb * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
         const unsigned py = p / a.inW, px = p - py * a.inW;
         const PixelTrack r = track_pixel(px, py, inV, inN, a.inW, refV, refN, a.refW, a.refH, T, view, have_reference,
@@ -1047,6 +1135,7 @@ __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs
         result_map[px + py * a.refW] = r.result;   // full-resolution row stride on every level (cpp:512)
         accumulate(acc, r.result, r.error, r.J);
     }
+#endif
     ICP_STAMP(5);
     block_reduce_store<ICP_THREADS>(acc, partials_out + (size_t)vb * 32);
     ICP_STAMP(6);
@@ -1094,8 +1183,12 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
 constexpr unsigned ICP_TAIL_BLOCKS = 32;
+#ifndef KFH_TAIL_FAST_PATH
+#define KFH_TAIL_FAST_PATH 1
+#endif
 struct IcpTailArgs {
     float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
+    unsigned long long *trace;          // debugging (KFH_ICP_TAIL_TRACE), else nullptr
     unsigned long long timeout_ticks;   // of the 100 MHz wall clock (2 s; KFH_ICP_TAIL_TIMEOUT_TICKS for the error-path test)
     int final_ops;            // >= 0: the launch closes the frame's ICP loop with these control operations (k_icp_final's job)
     FrameLogEntry *log; ControlArgs ca;
@@ -1120,6 +1213,39 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
     __shared__ IcpShared sh;
     const bool writer = blockIdx.x == 0;
     const bool closes = t.final_ops >= 0;       // this launch also does k_icp_final's work (block 0, after the loop)
+    unsigned long long *trace = t.trace;        // debugging (KFH_ICP_TAIL_TRACE): stamps of block 0 / thread 0
+    ICP_STAMP(0);
+#if KFH_TAIL_FAST_PATH
+    // The usual case first, on a path of its own: the level converged before this launch (its previous iteration was skipped, so
+    // there is nothing to solve either).  Then every workgroup only has to learn that - one state record - and the writer hands the
+    // state on and closes the loop.  Written through the general loop below, this path began with that loop's set-up (spilled
+    // loop invariants, the row prefetch addresses ...), ran by every thread in front of the first barrier: 7.4 k cycles from entry
+    // to the verdict, 12.9 k in a build whose register allocation fell differently, for what is one load (profiles/r04_sweeps.md).
+    {
+        if (threadIdx.x == 0) {
+            const IcpState prev = a.iters[a.it - 1];      // (a.it >= 1: a level's first iterations have launches of their own)
+            sh.pose = prev.pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = prev.done[l];
+            sh.prev_executed = prev.executed;
+        }
+        __syncthreads();
+        if (!sh.prev_executed && sh.done[a.level]) {      // (uniform over the launch: every workgroup reads the same record)
+            ICP_STAMP(1);
+            if (!writer) return;
+            if ((int)threadIdx.x < t.n_its) {             // the records the skipped iterations would have written, one thread each
+                IcpState &o = a.iters[a.it + (int)threadIdx.x];
+                o.pose = sh.pose;
+                for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+                o.executed = 0;
+            }
+            ICP_STAMP(2);
+            if (closes) close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
+            ICP_STAMP(3);
+            return;
+        }
+        __syncthreads();                                  // (sh is rewritten by the general path)
+    }
+#endif
     for (int j = 0; j <= t.n_its; ++j) {
         const int it = a.it + j;
         const float *prev = t.part[(it + 1) & 1];
@@ -1130,6 +1256,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
             break;
         }
         const bool run = j == 0 ? icp_enter<false, false>(sh, a, it, prev, writer) : icp_enter<true, true>(sh, a, it, prev, writer);
+        if (j == 0) ICP_STAMP(1);
         if (!run) {
             // the level is done: the remaining iterations would only hand the state on (as their launches did)
             if (!writer) return;
@@ -1140,6 +1267,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
                 o.executed = 0;
             }
             if (!closes) return;
+            ICP_STAMP(2);
             break;
         }
         for (unsigned vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
@@ -1150,6 +1278,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
     }
     // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
     close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
+    ICP_STAMP(3);
 }
 
 // ---- side jobs ----------------------------------------------------------------------------------------------------
@@ -1563,6 +1692,17 @@ __global__ __launch_bounds__(256) void k_verify_div(float d, float r, unsigned l
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
         const float a = __builtin_bit_cast(float, (27u << 23) + (unsigned)i);
         bad += (__builtin_bit_cast(unsigned, a / d) != __builtin_bit_cast(unsigned, div_by_const(a, d, r))) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+// sqrtf(d) > t against d > bound for every non-negative float bit pattern (see sqrt_gt_bound in kf_math.h)
+__global__ __launch_bounds__(256) void k_verify_sqrt_bound(float t, float bound, unsigned long long *mismatches) {
+    const unsigned long long n = 1ull << 31;
+    unsigned bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float d = __builtin_bit_cast(float, (unsigned)i);
+        bad += ((sqrtf(d) > t) != (d > bound)) ? 1u : 0u;
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
@@ -2322,6 +2462,8 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
     k_control<<<1, 64, 0, s>>>(st, log, ops, a); launched("k_control");
 }
 
+static bool sqrt_bound_verified(float t);
+
 static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map,
                                  int it, int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV,
                                  const float4 *inN, unsigned inW, unsigned inH, const float4 *refV, const float4 *refN,
@@ -2331,6 +2473,10 @@ static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *par
     a.it = it; a.level = level; a.prev_level = prev_level; a.prev_nblocks = prev_nblocks; a.nblocks = nblocks;
     a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
     a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
+    a.dist2_max = sqrt_bound_verified(dist_threshold) ? sqrt_gt_bound(dist_threshold) : -1.f;
+    // py = (unsigned)((p + 0.5f) * RN(1 / inW)) is p / inW while p + 0.5 and the two roundings leave more than the 0.5 / inW
+    // between (p + 0.5) / inW and the next integer: certainly for p < 2^22
+    a.inv_inW = ((unsigned long long)inW * inH <= (1ull << 22)) ? 1.0f / (float)inW : 0.f;
     a.ray_order = nullptr; a.ray_cost = nullptr; a.ray_tiles_x = a.ray_tiles_y = 0; a.order_mode = 0;
     a.trace = nullptr;
     return a;
@@ -2401,7 +2547,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
     }
     static WaveTrace wt("KFH_ICP_TRACE");
     static const int trace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 10; }();
-    if (it == trace_it && !side) { a.trace = wt.arm(2, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter"); wt.dump(); return; } }
+    if (it == trace_it && !side) { a.trace = wt.arm(4, s); if (a.trace) { k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter"); wt.dump(); return; } }
     if (side && side->kind == SideWork::RAY_ORDER) {
         a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode;
         k_icp_iter_order<<<nblocks + 1, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter_order");
@@ -2425,7 +2571,10 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     t.timeout_ticks = ticks_env >= 0 ? (unsigned long long)ticks_env : 200000000ull;
     t.final_ops = ca ? final_ops : -1; t.log = log;
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
+    static WaveTrace wt("KFH_ICP_TAIL_TRACE");
+    t.trace = (ca && level == 0) ? wt.arm(2, s) : nullptr;
     k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t); launched("k_icp_tail");
+    if (t.trace) wt.dump();
 }
 
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
@@ -2502,6 +2651,43 @@ static bool verified_divisor(float d, hipStream_t s) {
     }
     cache.push_back(Entry{dev, d, ok});
     return ok;
+}
+
+// Is "sqrtf(d) > t  <=>  d > sqrt_gt_bound(t)" verified for this threshold on this device?  prepare_sqrt_bound (kfh_create) runs
+// k_verify_sqrt_bound over EVERY non-negative float bit pattern (2^31 of them: zeros, denormals, infinity and the NaNs included) with
+// the square root this library is compiled with; the frame path only looks the verdict up.  Not verified = the ICP association takes
+// the square root as the reference does (cpp:543).
+struct SqrtBoundEntry { int dev; float t; bool ok; };
+static std::vector<SqrtBoundEntry> g_sqrt_bounds;
+static std::mutex g_sqrt_bounds_mu;
+static bool sqrt_bound_verified(float t) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_sqrt_bounds_mu);
+    for (const SqrtBoundEntry &e : g_sqrt_bounds) if (e.dev == dev && e.t == t) return e.ok;
+    return false;
+}
+void prepare_sqrt_bound(float t, hipStream_t s) {
+    static const bool allow = [] { const char *e = getenv("KFH_EXACT_SQRT"); return !(e && e[0] == '0'); }();
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_sqrt_bounds_mu);
+    for (const SqrtBoundEntry &e : g_sqrt_bounds) if (e.dev == dev && e.t == t) return;
+    bool ok = false, ran = true;
+    const float bound = sqrt_gt_bound(t);
+    if (allow && bound >= 0.f) {
+        unsigned long long *dm = nullptr;
+        ran = hipMalloc(&dm, sizeof *dm) == hipSuccess;
+        if (ran) {
+            unsigned long long h = 1;
+            ran = hipMemsetAsync(dm, 0, sizeof *dm, s) == hipSuccess;
+            if (ran) { k_verify_sqrt_bound<<<8192, 256, 0, s>>>(t, bound, dm); ran = hipGetLastError() == hipSuccess; }
+            ran = ran && hipMemcpyAsync(&h, dm, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            hipFree(dm);
+            ok = ran && h == 0;
+        }
+    }
+    if (ran) g_sqrt_bounds.push_back(SqrtBoundEntry{dev, t, ok});      // (a check that could not run is not remembered)
 }
 
 // all three axes verified and every numerator pos * size below 2^24

@@ -8,9 +8,23 @@
 // GR_SVD::backsub) — restated from TooN's published sources, since TooN is not vendored.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #define KF_HD __host__ __device__ __forceinline__
+// KFH_SOLVE_STAMPS=1 (diagnostic builds only): cycle stamps inside the solve / pose update of thread 0, written behind the
+// stamps of KFH_ICP_TRACE (profiles/icp_trace.py prints them)
+#ifndef KFH_SOLVE_STAMPS
+#define KFH_SOLVE_STAMPS 0
+#endif
+#if KFH_SOLVE_STAMPS && defined(__HIP_DEVICE_COMPILE__)
+#define KF_SOLVE_STAMP(tr, i, dep) do { if (tr) { asm volatile("" : : "v"(dep)); (tr)[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define KF_SOLVE_STAMP(tr, i, dep) do { } while (0)
+#endif
+#ifndef KFH_SOLVE_LEAN
+#define KFH_SOLVE_LEAN 1      // leaner fp64 solve / exponential / pose product on the single-thread path between two ICP associations
+#endif
 
 namespace kf {
 
@@ -36,6 +50,18 @@ KF_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 KF_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 KF_HD float length3(f3 v) { return sqrtf(dot3(v, v)); }
 KF_HD f3 normalize3(f3 v) { const float inv = 1.0f / sqrtf(dot3(v, v)); return scale3(v, inv); }
+
+// sqrtf(d) > t decided without the square root: the largest float X with sqrtf(X) <= t, so that for EVERY float d (NaN included,
+// both comparisons are then false)  sqrtf(d) > t  <=>  d > X  - the correctly rounded square root is monotonic.  Found from t * t by
+// stepping through neighbouring floats with the host's sqrtf (IEEE); the device's own square root is held to it for all 2^31
+// non-negative floats before the bound is used (k_verify_sqrt_bound).  Returns -1 when no such X >= 0 exists (t < 0 or NaN).
+inline float sqrt_gt_bound(float t) {
+    if (!(t >= 0.0f) || !(t < 1.8e19f)) return -1.0f;       // (t * t must stay finite)
+    float x = t * t;
+    for (int i = 0; i < 8 && sqrtf(x) > t; ++i) x = nextafterf(x, -1.0f);
+    for (int i = 0; i < 8 && sqrtf(nextafterf(x, INFINITY)) <= t; ++i) x = nextafterf(x, INFINITY);
+    return (sqrtf(x) <= t && sqrtf(nextafterf(x, INFINITY)) > t) ? x : -1.0f;
+}
 
 // commons.h:331-341
 KF_HD f3 xform(const M4 &M, f3 v) {
@@ -74,6 +100,25 @@ KF_HD M4 matmul(const M4 &A, const M4 &B) {
         }
     return R;
 }
+
+// matmul(A, B) for two rigid motions - last rows (0, 0, 0, 1), which the caller has checked - without the 65 operations whose
+// operands are those zeros and ones: for finite entries the sums below are the values of the general loop (0 + a b = a b,
+// x + a 0 = x, 0 b + ... + 1 b3 = b3; only the sign of a zero result can differ).  Used for pose <- exp(x) * pose (commons.h:404).
+KF_HD M4 matmul_rigid(const M4 &A, const M4 &B) {
+    M4 R;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 4; ++c) {
+            float acc = A.m[r][0] * B.m[0][c];
+            acc += A.m[r][1] * B.m[1][c];
+            acc += A.m[r][2] * B.m[2][c];
+            if (c == 3) acc += A.m[r][3];
+            R.m[r][c] = acc;
+        }
+    }
+    R.m[3][0] = 0.0f; R.m[3][1] = 0.0f; R.m[3][2] = 0.0f; R.m[3][3] = 1.0f;
+    return R;
+}
+KF_HD bool last_row_is_rigid(const M4 &A) { return A.m[3][0] == 0.0f && A.m[3][1] == 0.0f && A.m[3][2] == 0.0f && A.m[3][3] == 1.0f; }
 
 // commons.h:365-371: Gauss elimination with partial pivoting against the identity (float storage,
 // row multiplier held in double as TooN does), then back substitution.
@@ -147,6 +192,18 @@ KF_HD M4 se3_exp_to_m4(const double mu[6]) {
             A = 1.0 - theta_sq * C;
             B = 0.5 - 0.25 * one_6th * theta_sq;
         } else {
+#if KFH_SOLVE_LEAN
+            if (theta_sq < 1e-3) {
+                // the same three series cut after s^3: the first neglected terms (s^4 / 9!, 2 s^4 / 10!, 6 s^4 / 11!) are below 3e-18 for
+                // s < 1e-3, under half an ulp of the double result.  An ICP update turns the camera by milliradians (s ~ 1e-6 ... 1e-4),
+                // so this is the branch a frame takes: nine fused multiply-adds on the one thread that every block waits for, instead
+                // of ~75 operations of the nine-term chains below.
+                const double s = theta_sq;
+                A = __builtin_fma(s, __builtin_fma(s, __builtin_fma(s, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+                B = __builtin_fma(s, __builtin_fma(s, __builtin_fma(s, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
+                C = __builtin_fma(s, __builtin_fma(s, __builtin_fma(s, -1.0 / 362880.0, 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+            } else
+#endif
             if (theta_sq < 0.25) {
                 // sin(t)/t, (1 - cos t)/t^2 and (1 - sin(t)/t)/t^2 from their alternating series in s = t^2 (nine terms:
                 // the first neglected one is below 1e-22 for s < 0.25), i.e. to a couple of ulps of double - the values
@@ -267,11 +324,23 @@ __host__ __device__ inline double pivot_reciprocal(double d) {
 #endif
 }
 
-__host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
+__host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsigned long long *stamps = nullptr) {
     double L[6][6], d[6], b[6];
     double c_f2 = 0.0, tr = 0.0;
     {
         int p = 6;
+#if KFH_SOLVE_LEAN
+        double off2 = 0.0;      // |C|_F^2 = sum of the squared diagonal + twice the squared off-diagonal entries: 22 fused multiply-adds
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                const double v = vals[p]; ++p;
+                L[c][r] = v;   // lower triangle holds C
+                if (c == r) c_f2 = __builtin_fma(v, v, c_f2); else off2 = __builtin_fma(v, v, off2);
+            }
+        c_f2 = __builtin_fma(2.0, off2, c_f2);
+#else
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -280,6 +349,7 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
                 L[c][r] = v;   // lower triangle holds C
                 c_f2 += (c == r) ? v * v : 2.0 * v * v;
             }
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) { b[i] = vals[i]; tr += L[i][i]; }
@@ -287,6 +357,29 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
     const double tiny = tr * 1e-9;
     // in-place LDL^T: L[i][j] (i > j) becomes the unit-lower factor, d the diagonal
     double invd[6], dmin = 1e300;
+#if KFH_SOLVE_LEAN
+    // row j scaled by the pivots once (u[k] = L[j][k] d[k]) and every inner product as a chain of fused multiply-adds: 95 operations
+    // on the serial path instead of 150 (the solution only has to be good to ~1e-12; its bits are not the reference's anyway)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double u[6];
+        double dj = L[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) { u[k] = L[j][k] * d[k]; dj = __builtin_fma(-L[j][k], u[k], dj); }
+        if (!(dj > tiny)) return false;
+        d[j] = dj;
+        dmin = dj < dmin ? dj : dmin;
+        const double inv = pivot_reciprocal(dj);
+        invd[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = L[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v = __builtin_fma(-L[i][k], u[k], v);
+            L[i][j] = v * inv;
+        }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double dj = L[j][j];
@@ -305,6 +398,8 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
             L[i][j] = v * inv;
         }
     }
+#endif
+    KF_SOLVE_STAMP(stamps, 9, (float)(L[5][4] + d[5]));
     // M = L^-1 (unit lower triangular), column by column
     double M[6][6], m_f2 = 6.0;
 #pragma unroll
@@ -312,15 +407,23 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
             double v = -L[r][c];
+#if KFH_SOLVE_LEAN
+#pragma unroll
+            for (int k = c + 1; k < r; ++k) v = __builtin_fma(-L[r][k], M[k][c], v);
+            M[r][c] = v;
+            m_f2 = __builtin_fma(v, v, m_f2);
+#else
 #pragma unroll
             for (int k = c + 1; k < r; ++k) v -= L[r][k] * M[k][c];
             M[r][c] = v;
             m_f2 += v * v;
+#endif
         }
     // Certificate: C^-1 = M^T D^-1 M, so |C^-1|_2 <= |M|_F^2 / d_min, and |C|_2 <= |C|_F: when their product is below 5e5
     // no singular value can fall under the reference's max/1e6 cut-off and the plain inverse is what the reference
     // computes too.  The bound over-estimates the condition number ~4x on real ICP systems (cond ~1e3, bound ~4e3:
     // profiles/r01_sweeps.md), so everything up to cond ~1e5 stays on this path.
+    KF_SOLVE_STAMP(stamps, 10, (float)m_f2);
     if (!(c_f2 * (m_f2 * m_f2) < (5e5 * 5e5) * (dmin * dmin))) return false;
     // x = M^T D^-1 M b
     double y[6];
@@ -328,14 +431,14 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6]) {
     for (int i = 0; i < 6; ++i) {
         double v = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) v += M[i][k] * b[k];
+        for (int k = 0; k < i; ++k) v = KFH_SOLVE_LEAN ? __builtin_fma(M[i][k], b[k], v) : v + M[i][k] * b[k];
         y[i] = v * invd[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) v += M[k][i] * y[k];
+        for (int k = i + 1; k < 6; ++k) v = KFH_SOLVE_LEAN ? __builtin_fma(M[k][i], y[k], v) : v + M[k][i] * y[k];
         x[i] = v;
     }
     return true;

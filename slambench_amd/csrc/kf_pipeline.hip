@@ -748,6 +748,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     kfh_reset(c);
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     launch::prepare_bilateral_division(e_delta, c->stream);
+    launch::prepare_sqrt_bound(dist_threshold, c->stream);         // the ICP association's length(diff) > dist_threshold (cpp:543)
     if (const int verdict = launch::reduction_verified(c->stream); verdict != 1) {      // (fatal: every ICP sum of this backend goes through that reduction)
         g_last_error = verdict == 0 ? "kfh_create: the ICP block reduction failed its self-check on this device (k_verify_reduce)"
                                     : "kfh_create: the self-check of the ICP block reduction could not be run (HIP error: allocation, launch or wait)";
