@@ -57,11 +57,12 @@ MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, float(os.environ.get("KFH_DEBUG_ICP_THRE
 V_FRAMES = 2            # frames after the cpu_baseline prefix on which the oracle counts V (distinct voxels a raycast samples)
 
 
-def icp_launches(pyramid, head=4):
-    """launches of a frame's ICP loop: per level the first `head` iterations one each, the rest (if >= 2) share one
-    (kf_pipeline.hip tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
+def icp_launches(pyramid, heads=(4, 3)):
+    """launches of a frame's ICP loop: per level the first `head` iterations one each (4 on level 0, 3 on the coarser ones), the
+    rest (if >= 2) share one (kf_pipeline.hip tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
     n, closed = 0, False
     for level, its in enumerate(pyramid):
+        head = heads[min(level, len(heads) - 1)]
         tail = its - head if its - head >= 2 else 0
         n += its - tail + (1 if tail else 0)
         closed = closed or (tail > 0 and level == 0)

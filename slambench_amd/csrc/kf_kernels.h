@@ -162,7 +162,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              FrameLogEntry *log, int final_ops, const ControlArgs *ca, hipStream_t s);   // ca != nullptr: also does icp_final's work
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, hipStream_t s);   // ca != nullptr: also does icp_final's work
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

@@ -943,18 +943,28 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     __syncthreads();
     const float inv_tx = 1.0f / (float)tiles_x;
     constexpr int KEEP = RAY_ORDER_KEPT_TILES / 1024;     // keys of up to this many tiles stay in registers between the passes
+    // (the kept keys are indexed by unrolled constants only: a run-time index would put the array into scratch memory, and a kernel
+    // that declares scratch costs every launch 0.2-0.5 us - these blocks ride on the ICP launches, profiles/r04_launch_cost.txt)
     unsigned keys[KEEP];
-    int slot = 0;
-    for (unsigned i = tid; i < n; i += nthr, ++slot) {
+    auto classify = [&](unsigned i) {
         const int ty = (int)(((float)i + 0.5f) * inv_tx), tx = (int)i - ty * (int)tiles_x;   // exact: i < 2^23
         unsigned m = cost[i];
         if (mode == 0) m >>= 2;
         const unsigned b = m < RAY_COST_BUCKETS - 1 ? m : RAY_COST_BUCKETS - 1;
         const unsigned r = R == 1 ? 0u : ((unsigned)(tx >> SS) + super_x * (unsigned)(ty >> SS) + (unsigned)(ty >> SS)) % RAY_REGIONS;
-        const unsigned k = b | (r << 8);        // (b < 256)
-        if (staged && slot < KEEP) keys[slot] = k; else key[i] = k;
         atomicAdd(&sh.hist[r][b], 1u);
+        return b | (r << 8);        // (b < 256)
+    };
+#pragma unroll
+    for (int slot = 0; slot < KEEP; ++slot) {
+        const unsigned i = tid + (unsigned)slot * nthr;
+        keys[slot] = 0;
+        if (i < n) {
+            const unsigned k = classify(i);
+            if (staged) keys[slot] = k; else key[i] = k;
+        }
     }
+    for (unsigned i = tid + (unsigned)KEEP * nthr; i < n; i += nthr) key[i] = classify(i);
     __syncthreads();
     // per class: offs[b] = number of its tiles in buckets above b.  One wave per class, one lane per bucket: an inclusive
     // scan of the reversed histogram by six shuffle steps (no barrier), minus the own count.
@@ -974,9 +984,7 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
     __syncthreads();
     unsigned cmin = sh.count[0];
     for (unsigned q = 1; q < R; ++q) cmin = cmin < sh.count[q] ? cmin : sh.count[q];
-    slot = 0;
-    for (unsigned i = tid; i < n; i += nthr, ++slot) {
-        const unsigned k = (staged && slot < KEEP) ? keys[slot] : key[i];
+    auto place = [&](unsigned i, unsigned k) {
         const unsigned r = k >> 8;
         const unsigned pos = atomicAdd(&sh.offs[r][k & 255u], 1u);       // rank of the tile inside its class
         // slot of (class r, rank pos) when the classes take turns and a class that has run out is passed over
@@ -991,7 +999,13 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
         }
         order[R == 1 ? pos : s_] = i;
         cost[i] = 0;
+    };
+#pragma unroll
+    for (int slot = 0; slot < KEEP; ++slot) {
+        const unsigned i = tid + (unsigned)slot * nthr;
+        if (i < n) place(i, staged ? keys[slot] : key[i]);
     }
+    for (unsigned i = tid + (unsigned)KEEP * nthr; i < n; i += nthr) place(i, key[i]);
 }
 
 __global__ __launch_bounds__(1024) void k_ray_order(unsigned *__restrict__ order, unsigned *__restrict__ cost, unsigned tiles_x, unsigned tiles_y,
@@ -1183,9 +1197,7 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
 constexpr unsigned ICP_TAIL_BLOCKS = 32;
-#ifndef KFH_TAIL_FAST_PATH
-#define KFH_TAIL_FAST_PATH 1
-#endif
+
 struct IcpTailArgs {
     float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
     unsigned long long *trace;          // debugging (KFH_ICP_TAIL_TRACE), else nullptr
@@ -1209,75 +1221,68 @@ __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, u
     __syncthreads();
 }
 
+// The iterations of the launch that do run (rare): a routine of its own, NOT inlined, so that its set-up - loop invariants, spilled
+// addresses, the association's constants - cannot be hoisted in front of the verdict the usual case leaves with (as one loop the
+// kernel spent 7.4 k - 12.9 k cycles between entry and that verdict, depending on how the register allocation fell; 1.5 k now).
+// Enters with the state of iteration a.it in `sh` and that iteration due.  Returns true if the caller (the writer workgroup of a
+// closing launch) is to close the frame's ICP loop.
+__device__ __forceinline__ bool icp_tail_iterations(IcpShared &sh, const IcpIterArgs &a, const IcpTailArgs &t) {
+    const bool writer = blockIdx.x == 0;
+    const bool closes = t.final_ops >= 0;
+    for (int j = 0;; ++j) {
+        const int it = a.it + j;
+        for (unsigned vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
+            icp_track_block(sh, a, vb, t.part[it & 1]);
+            __syncthreads();                                // block_reduce_store's LDS rows are reused
+        }
+        if (j + 1 < t.n_its || closes) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts, t.timeout_ticks);
+        if (j + 1 == t.n_its) {
+            // every queued iteration ran: the update of the last one, as k_icp_final would apply it
+            if (!(closes && writer)) return false;
+            icp_advance<true, true>(sh, a.st, a.iters, t.part[it & 1], it + 1, a.level, a.nblocks, a.icp_threshold, true);
+            return true;
+        }
+        if (icp_enter<true, true>(sh, a, it + 1, t.part[it & 1], writer)) continue;
+        // the level is done: the remaining iterations would only hand the state on (as their launches did)
+        if (!writer) return false;
+        if ((int)threadIdx.x < a.it + t.n_its - (it + 2)) {     // one thread per record
+            IcpState &o = a.iters[it + 2 + (int)threadIdx.x];
+            o.pose = sh.pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+            o.executed = 0;
+        }
+        return closes;
+    }
+}
+
+// AHEAD: the partial rows of the previous launch are requested before the state record (right when the iteration before this
+// launch usually ran, i.e. when the launch usually has a system to solve: tails that begin early in a level)
+template <bool AHEAD>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(IcpIterArgs a, IcpTailArgs t) {
     __shared__ IcpShared sh;
     const bool writer = blockIdx.x == 0;
     const bool closes = t.final_ops >= 0;       // this launch also does k_icp_final's work (block 0, after the loop)
     unsigned long long *trace = t.trace;        // debugging (KFH_ICP_TAIL_TRACE): stamps of block 0 / thread 0
     ICP_STAMP(0);
-#if KFH_TAIL_FAST_PATH
-    // The usual case first, on a path of its own: the level converged before this launch (its previous iteration was skipped, so
-    // there is nothing to solve either).  Then every workgroup only has to learn that - one state record - and the writer hands the
-    // state on and closes the loop.  Written through the general loop below, this path began with that loop's set-up (spilled
-    // loop invariants, the row prefetch addresses ...), ran by every thread in front of the first barrier: 7.4 k cycles from entry
-    // to the verdict, 12.9 k in a build whose register allocation fell differently, for what is one load (profiles/r04_sweeps.md).
-    {
-        if (threadIdx.x == 0) {
-            const IcpState prev = a.iters[a.it - 1];      // (a.it >= 1: a level's first iterations have launches of their own)
-            sh.pose = prev.pose;
-            for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = prev.done[l];
-            sh.prev_executed = prev.executed;
+    // the state entering the first queued iteration (the update from the previous launch's sums, if it ran) - and, almost always,
+    // the verdict that the level has converged: the workgroups leave, the writer hands the state on and closes the loop
+    const bool run = icp_enter<false, AHEAD>(sh, a, a.it, t.part[(a.it + 1) & 1], writer);
+    ICP_STAMP(1);
+    bool close = closes && writer;
+    if (!run) {
+        if (!writer) return;
+        if ((int)threadIdx.x < t.n_its - 1) {       // the records the skipped iterations would have written, one thread each
+            IcpState &o = a.iters[a.it + 1 + (int)threadIdx.x];
+            o.pose = sh.pose;
+            for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
+            o.executed = 0;
         }
-        __syncthreads();
-        if (!sh.prev_executed && sh.done[a.level]) {      // (uniform over the launch: every workgroup reads the same record)
-            ICP_STAMP(1);
-            if (!writer) return;
-            if ((int)threadIdx.x < t.n_its) {             // the records the skipped iterations would have written, one thread each
-                IcpState &o = a.iters[a.it + (int)threadIdx.x];
-                o.pose = sh.pose;
-                for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-                o.executed = 0;
-            }
-            ICP_STAMP(2);
-            if (closes) close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
-            ICP_STAMP(3);
-            return;
-        }
-        __syncthreads();                                  // (sh is rewritten by the general path)
-    }
-#endif
-    for (int j = 0; j <= t.n_its; ++j) {
-        const int it = a.it + j;
-        const float *prev = t.part[(it + 1) & 1];
-        if (j == t.n_its) {
-            // every queued iteration ran (rare): the update of the last one, as k_icp_final would apply it
-            if (!(closes && writer)) return;
-            icp_advance<true, true>(sh, a.st, a.iters, prev, it, a.level, a.nblocks, a.icp_threshold, true);
-            break;
-        }
-        const bool run = j == 0 ? icp_enter<false, false>(sh, a, it, prev, writer) : icp_enter<true, true>(sh, a, it, prev, writer);
-        if (j == 0) ICP_STAMP(1);
-        if (!run) {
-            // the level is done: the remaining iterations would only hand the state on (as their launches did)
-            if (!writer) return;
-            if ((int)threadIdx.x < a.it + t.n_its - (it + 1)) {     // one thread per record
-                IcpState &o = a.iters[it + 1 + (int)threadIdx.x];
-                o.pose = sh.pose;
-                for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-                o.executed = 0;
-            }
-            if (!closes) return;
-            ICP_STAMP(2);
-            break;
-        }
-        for (unsigned vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
-            icp_track_block(sh, a, vb, t.part[it & 1]);
-            __syncthreads();                                // block_reduce_store's LDS rows are reused
-        }
-        if (j + 1 < t.n_its || closes) grid_barrier(t.barrier, (unsigned)(j + 1) * gridDim.x, t.timeouts, t.timeout_ticks);
+        ICP_STAMP(2);
+    } else {
+        close = icp_tail_iterations(sh, a, t);
     }
     // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
-    close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
+    if (close) close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
     ICP_STAMP(3);
 }
 
@@ -2559,7 +2564,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              FrameLogEntry *log, int final_ops, const ControlArgs *ca, hipStream_t s) {
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, hipStream_t s) {
     // (the launch before `it` is an ordinary one of the same level: prev_level = level, prev_nblocks = nblocks)
     IcpIterArgs a = make_icp_args(st, iters, (it + 1) & 1 ? part1 : part0, it & 1 ? part1 : part0, result_map, it, level, level,
                                   nblocks, nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
@@ -2573,7 +2578,10 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
     static WaveTrace wt("KFH_ICP_TAIL_TRACE");
     t.trace = (ca && level == 0) ? wt.arm(2, s) : nullptr;
-    k_icp_tail<<<nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS, ICP_THREADS, 0, s>>>(a, t); launched("k_icp_tail");
+    const unsigned wgs = nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS;
+    if (rows_ahead) k_icp_tail<true><<<wgs, ICP_THREADS, 0, s>>>(a, t);
+    else k_icp_tail<false><<<wgs, ICP_THREADS, 0, s>>>(a, t);
+    launched("k_icp_tail");
     if (t.trace) wt.dump();
 }
 

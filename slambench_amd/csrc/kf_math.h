@@ -325,7 +325,7 @@ __host__ __device__ inline double pivot_reciprocal(double d) {
 }
 
 __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsigned long long *stamps = nullptr) {
-    double L[6][6], d[6], b[6];
+    double L[6][6], d[6];
     double c_f2 = 0.0, tr = 0.0;
     {
         int p = 6;
@@ -352,7 +352,7 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsi
 #endif
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { b[i] = vals[i]; tr += L[i][i]; }
+    for (int i = 0; i < 6; ++i) tr += L[i][i];
     if (!(tr > 0.0)) return false;
     const double tiny = tr * 1e-9;
     // in-place LDL^T: L[i][j] (i > j) becomes the unit-lower factor, d the diagonal
@@ -425,8 +425,12 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsi
     // profiles/r01_sweeps.md), so everything up to cond ~1e5 stays on this path.
     KF_SOLVE_STAMP(stamps, 10, (float)m_f2);
     if (!(c_f2 * (m_f2 * m_f2) < (5e5 * 5e5) * (dmin * dmin))) return false;
-    // x = M^T D^-1 M b
-    double y[6];
+    // x = M^T D^-1 M b  (b is read where it is used: held from the top, its six doubles are what pushed the factorisation
+    // above the 128 registers of a 1024-thread block and two of its values into scratch memory - and a kernel that
+    // declares scratch costs every launch 0.2-0.5 us, profiles/r04_launch_cost.txt)
+    double y[6], b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = vals[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = b[i];

@@ -336,10 +336,14 @@ static void fill_side_pyramid(const kfh_context *c, const NextFrameWork &nw, Sid
 }
 
 // How many of a level's last iterations share one launch (k_icp_tail): everything after the first `icp_tail_head`
-// (KFH_ICP_TAIL_HEAD, one value or a list by level, default 4; 0 = every iteration gets its own launch), if that is at least two.
+// (KFH_ICP_TAIL_HEAD, one value or a list by level; 0 = every iteration gets its own launch), if that is at least two.  Default: 4 on
+// level 0, 3 on the coarser levels.  A launch costs >= 4.4 us however little it does (profiles/r04_launch_cost.txt) and the loop
+// stops a level after 3 iterations in ~90 % of the frames: on level 1 (5 iterations) the tail then replaces the launch that finds
+// the level converged AND the one after it (cfg2 ICP loop 110.7 -> 108.5 us); on level 0 a third of a microsecond either way
+// (an iteration that does run inside the tail costs ~37 us there against ~14 on level 1), so its fourth iteration keeps its launch.
 static int tail_length(const kfh_context *c, int level) {
     const int n = c->iterations[level];
-    const int head = c->icp_tail_head.empty() ? 4 : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
+    const int head = c->icp_tail_head.empty() ? (level == 0 ? 4 : 3) : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
     if (head <= 0 || n - head < 2) return 0;
     return n - head;
 }
@@ -457,7 +461,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             closed = level == 0 && fold_env;      // the loop's last launch: it applies the final update and end_ops too
             launch::icp_tail(c->d_state, c->d_icp, part[0], part[1], c->d_result, it, n_tail, level, nb, c->d_inV[level],
                              c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold, dist_threshold,
-                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, c->stream);
+                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, /* rows_ahead: the iteration before the launch usually ran */ n_plain < 4, c->stream);
             it += n_tail;
         }
     }

@@ -187,8 +187,11 @@ def test_shared_late_iteration_launch_equals_one_launch_per_iteration(hip, kfmod
     k = list(stream.k)
     res = (128, 128, 128)
     runs = {}
-    for head in ("0", "4", "1"):      # 0: no tail launches; 1: every level's iterations 1.. share a launch
-        monkeypatch.setenv("KFH_ICP_TAIL_HEAD", head)
+    for head in ("0", "4", "1", ""):      # 0: no tail launches; 1: every level's iterations 1.. share a launch; "": the default (4 on level 0, 3 above)
+        if head:
+            monkeypatch.setenv("KFH_ICP_TAIL_HEAD", head)
+        else:
+            monkeypatch.delenv("KFH_ICP_TAIL_HEAD")
         g = kfmod.Kfusion((W, H), res, util.VOL_DIM, stream.init_pos)
         for f in range(FRAMES):
             g.compute_frame(stream.depth_mm[f], (W, H), k, 1, 1, icp_threshold, util.MU, f)
@@ -199,7 +202,7 @@ def test_shared_late_iteration_launch_equals_one_launch_per_iteration(hip, kfmod
         g.close()
     if icp_threshold == 0.0:
         assert runs["0"][4] == [10 * (FRAMES - 0), 5 * FRAMES, 4 * FRAMES]
-    for head in ("4", "1"):
+    for head in ("4", "1", ""):
         assert same_bits(runs["0"][0], runs[head][0]), head
         assert runs["0"][1:3] == runs[head][1:3] and runs["0"][4] == runs[head][4], head
         assert np.array_equal(runs["0"][3], runs[head][3]) and np.array_equal(runs["0"][5], runs[head][5]), head
