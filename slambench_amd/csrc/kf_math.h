@@ -400,6 +400,49 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsi
     }
 #endif
     KF_SOLVE_STAMP(stamps, 9, (float)(L[5][4] + d[5]));
+#if KFH_SOLVE_LEAN
+    // |L^-1|_F^2 for the certificate, column by column with nothing kept (column c of M = L^-1 solves L m = e_c and needs only its
+    // own earlier entries), and x by substitution with L itself - L y = b, z = D^-1 y, L^T x = z - instead of x = M^T D^-1 M b with
+    // all of M held: the same operation count, 15 doubles (30 registers) fewer at the peak.  The 1024-thread ICP blocks have 128
+    // registers per thread; what this routine does not need stays free for whatever its caller keeps live around it (inside the
+    // iteration loop of k_icp_level the old form spilled ~40 values into its dependent chain).
+    double m_f2 = 6.0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        double m[6];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            double v = -L[r][c];
+#pragma unroll
+            for (int k = c + 1; k < r; ++k) v = __builtin_fma(-L[r][k], m[k], v);
+            m[r] = v;
+            m_f2 = __builtin_fma(v, v, m_f2);
+        }
+    }
+    // Certificate: C^-1 = M^T D^-1 M, so |C^-1|_2 <= |M|_F^2 / d_min, and |C|_2 <= |C|_F: when their product is below 5e5
+    // no singular value can fall under the reference's max/1e6 cut-off and the plain inverse is what the reference
+    // computes too.  The bound over-estimates the condition number ~4x on real ICP systems (cond ~1e3, bound ~4e3:
+    // profiles/r01_sweeps.md), so everything up to cond ~1e5 stays on this path.
+    KF_SOLVE_STAMP(stamps, 10, (float)m_f2);
+    if (!(c_f2 * (m_f2 * m_f2) < (5e5 * 5e5) * (dmin * dmin))) return false;
+    // (b is read where it is used: held from the top, its six doubles pushed the factorisation above the 128 registers and two
+    // of its values into scratch memory - and a kernel that declares scratch costs every launch 0.2-0.5 us, profiles/r04_launch_cost.txt)
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = vals[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = __builtin_fma(-L[i][k], y[k], v);
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i] * invd[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v = __builtin_fma(-L[k][i], x[k], v);
+        x[i] = v;
+    }
+#else
     // M = L^-1 (unit lower triangular), column by column
     double M[6][6], m_f2 = 6.0;
 #pragma unroll
@@ -407,17 +450,10 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsi
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
             double v = -L[r][c];
-#if KFH_SOLVE_LEAN
-#pragma unroll
-            for (int k = c + 1; k < r; ++k) v = __builtin_fma(-L[r][k], M[k][c], v);
-            M[r][c] = v;
-            m_f2 = __builtin_fma(v, v, m_f2);
-#else
 #pragma unroll
             for (int k = c + 1; k < r; ++k) v -= L[r][k] * M[k][c];
             M[r][c] = v;
             m_f2 += v * v;
-#endif
         }
     // Certificate: C^-1 = M^T D^-1 M, so |C^-1|_2 <= |M|_F^2 / d_min, and |C|_2 <= |C|_F: when their product is below 5e5
     // no singular value can fall under the reference's max/1e6 cut-off and the plain inverse is what the reference
@@ -435,16 +471,17 @@ __host__ __device__ inline bool solve6_ldlt(const float *vals, double x[6], unsi
     for (int i = 0; i < 6; ++i) {
         double v = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) v = KFH_SOLVE_LEAN ? __builtin_fma(M[i][k], b[k], v) : v + M[i][k] * b[k];
+        for (int k = 0; k < i; ++k) v += M[i][k] * b[k];
         y[i] = v * invd[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) v = KFH_SOLVE_LEAN ? __builtin_fma(M[k][i], y[k], v) : v + M[k][i] * y[k];
+        for (int k = i + 1; k < 6; ++k) v += M[k][i] * y[k];
         x[i] = v;
     }
+#endif
     return true;
 }
 
