@@ -156,10 +156,7 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s,
-              int level_its = 1, float *part0 = nullptr, float *part1 = nullptr);   // level_its > 1: the iterations it .. it + level_its - 1 in ONE launch (k_icp_level)
-// largest number of ICP blocks a level may have to run as one launch (its workgroups must be resident together)
-unsigned icp_level_max_blocks();
+              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s);
 // the last n_its iterations of a level (it .. it + n_its - 1, all after an ordinary launch of that level) in one launch;
 // if it is the last launch of the frame's loop it can apply the final update and the control operations too
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,

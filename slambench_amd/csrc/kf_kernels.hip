@@ -512,9 +512,7 @@ __device__ __forceinline__ void halve_dpp(const float (&in)[2 * N], float (&out)
     }
 }
 
-// COHERENT: the row is written with agent-scope stores (write-through: other workgroups of the SAME launch read it after a grid
-// barrier, k_icp_level), otherwise with plain ones (read by the next launch)
-template <int NT, bool COHERENT = false>
+template <int NT>
 __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__restrict__ partial) {
     __shared__ float sm[NT / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -541,8 +539,7 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[32], float *__re
         float t = sm[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) t += sm[w][threadIdx.x];
-        if (COHERENT) __hip_atomic_store(partial + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else partial[threadIdx.x] = t;
+        partial[threadIdx.x] = t;
     }
 }
 
@@ -722,8 +719,7 @@ __global__ void k_check_pose(M4 *pose, const M4 *oldPose, const float *reduction
 // =====================================================================================
 __device__ __forceinline__ void track_begin(DevState *__restrict__ st, bool track_frame, const float k[4]) {
     for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->level_done[l] = track_frame ? 0 : 1;
-    // arrival counters of the grid barriers (k_icp_tail, k_icp_level): cleared here, in a launch that precedes the frame's ICP loop -
-    // the loop's first launch may itself be one that uses them
+    // arrival counters of k_icp_tail's grid barrier: cleared here, by the one thread of a launch that precedes the frame's ICP loop
     for (int l = 0; l < KFH_MAX_LEVELS; ++l) st->tail_barrier[l] = 0;
     st->timeouts_at_track_begin = __hip_atomic_load(&st->barrier_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (track_frame) {
@@ -857,7 +853,7 @@ __device__ __forceinline__ void icp_advance(IcpShared &sh, DevState *__restrict_
         if (it == 0) {
             sh.pose = st->pose;
             for (int l = 0; l < KFH_MAX_LEVELS; ++l) sh.done[l] = st->level_done[l];
-            sh.prev_executed = 0;       // (the grid-barrier counters of k_icp_tail / k_icp_level were cleared by track_begin)
+            sh.prev_executed = 0;       // (the grid-barrier counters of k_icp_tail were cleared by track_begin)
         } else {
             IcpState prev;
             if (COHERENT) {
@@ -1106,7 +1102,6 @@ __device__ __forceinline__ int associate_accumulate(float (&acc)[32], float4 n4,
 }
 
 // association + partial sums of ICP block `vb` (of a.nblocks) with the pose in sh
-template <bool COHERENT_ROW = false>
 __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs &a, unsigned vb, float *partials_out) {
     DevState *__restrict__ st = a.st;
     unsigned long long *trace = a.trace;
@@ -1157,7 +1152,7 @@ __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs
     }
 #endif
     ICP_STAMP(5);
-    block_reduce_store<ICP_THREADS, COHERENT_ROW>(acc, partials_out + (size_t)vb * 32);
+    block_reduce_store<ICP_THREADS>(acc, partials_out + (size_t)vb * 32);
     ICP_STAMP(6);
 }
 
@@ -1176,137 +1171,6 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_or
     __shared__ IcpShared sh;
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
-    ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
-}
-
-// ---- level launch -------------------------------------------------------------------------------------------------
-// A launch costs >= 4.4 us however little it does (profiles/r04_launch_cost.txt), and a coarse pyramid level is 19 or 75 workgroups
-// whose iteration is ~3 us of association and reduction.  k_icp_level runs ALL iterations of such a level in one launch: one
-// workgroup per ICP block (the blocks, pixels and partial rows of the launch-per-iteration schedule, hence its bits), and between
-// two iterations a grid barrier that needs no cache write-back: the partial rows are written through with agent-scope stores, the
-// writing wave waits for their acknowledgement (s_waitcnt) before it counts itself in, and everybody reads the rows with
-// agent-scope loads - store + barrier + sum of all rows: 1.8 us for 19 workgroups, 2.8 us for 75 (profiles/r04_grid_barrier.txt;
-// the fence-based barrier of k_icp_tail: 2.2 / 5.1; no stale row in 1e9 reads).  Every workgroup adds up the rows and solves for itself
-// - same data, same instructions, same pose - so nothing but the rows crosses the barrier; the state stays in LDS from one
-// iteration to the next.  The level's LAST iteration leaves its rows to the next launch, as every level's last iteration does.
-// Side blocks (the next frame's preprocessing, the dispatch sorts) ride along exactly as on a one-iteration launch, with the whole
-// level to finish in.  The workgroups must be resident together: see kfh_create's reservation (barrier budget).
-struct IcpLevelArgs {
-    float *part[2];           // the two buffers of partial rows (iteration `it` writes part[it & 1])
-    int n_its;                // iterations of the level: a.it .. a.it + n_its - 1
-    unsigned *barrier, *timeouts;
-    unsigned long long timeout_ticks;
-};
-
-__device__ __forceinline__ void lean_grid_barrier(unsigned *counter, unsigned goal, unsigned *timeouts, unsigned long long timeout_ticks) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (this wave wrote the workgroup's row - lanes 0..31 of wave 0: once its stores are acknowledged the row is in memory)
-        __builtin_amdgcn_s_waitcnt(0);
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();       // 100 MHz
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < goal) {
-            if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(timeouts, 1u); break; }      // (the grid always drains)
-        }
-    }
-    __syncthreads();
-}
-
-// apply_update on the state in LDS, as a routine of its own (NOT inlined): inside k_icp_level's iteration loop the inlined solve
-// shared its 128 registers with whatever the compiler keeps live around the loop and spilled ~50 values into its dependent chain
-// ("rows + solve" 10.5 k cycles against ~6 k in a one-iteration launch); called, it has the registers to itself and the caller
-// saves what it holds around the call, off the chain.  Only the wave of thread 0 makes the call.  Bit 0: converged, bit 1: the
-// Jacobi fall-back ran.
-__device__ __attribute__((noinline)) int apply_update_in_lds(IcpShared *sh, float icp_threshold) {
-    M4 pose = sh->pose;
-    bool fast = true;
-    const bool converged = apply_update(pose, sh->red, icp_threshold, fast, sh->jacobi_ws);
-    sh->pose = pose;
-    return (converged ? 1 : 0) | (fast ? 0 : 2);
-}
-
-// The update of an iteration from the rows its workgroups just left (the second half of icp_advance, same sums in the same
-// order): sh.pose and sh.done[level] afterwards hold the state entering the next iteration.
-__device__ __forceinline__ void icp_solve_rows_coherent(IcpShared &sh, DevState *__restrict__ st, const float *rows, int level,
-                                                        unsigned nblocks, float icp_threshold, bool writer) {
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    constexpr int G = ICP_THREADS / 32;
-    float acc = 0.f;
-    for (unsigned b = (unsigned)g; b < nblocks; b += G)
-        acc += __hip_atomic_load(rows + (size_t)b * 32 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh.sm[g][c] = acc;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float v = sh.sm[0][threadIdx.x];
-#pragma unroll
-        for (int k = 1; k < G; ++k) v += sh.sm[k][threadIdx.x];
-        sh.red[threadIdx.x] = v;
-        if (writer) st->reduction[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int verdict = apply_update_in_lds(&sh, icp_threshold);
-        if (verdict & 1) sh.done[level] = 1;
-        if (writer) {
-            atomicAdd(&st->icp_iterations, 1ull);
-            atomicAdd(&st->icp_level_iterations[level], 1ull);
-            if (verdict & 2) atomicAdd(&st->solve_fallbacks, 1ull);
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void icp_level_block(IcpShared &sh, const IcpIterArgs &a, const IcpLevelArgs &t) {
-    const bool writer = blockIdx.x == 0;
-    // the state entering the level's first iteration: what the previous launch left (the update from the previous level's last
-    // iteration included), recorded like any launch's
-    unsigned long long *trace = a.trace;      // debugging (KFH_ICP_LEVEL_TRACE): stamps of block 0 / thread 0
-    bool run = icp_enter(sh, a, a.it, a.partials_prev, writer);
-    ICP_STAMP(7);
-    if (!run && writer && (int)threadIdx.x < t.n_its - 1) {      // nothing to do on this level: the records its other launches would leave
-        IcpState &o = a.iters[a.it + 1 + (int)threadIdx.x];
-        o.pose = sh.pose;
-        for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-        o.executed = 0;
-    }
-    IcpIterArgs la = a;
-    for (int j = 0; run; ++j) {
-        const int it = a.it + j;
-        // The base pointers of an iteration are "laundered" at its top: whatever derives from them - the view matrix, the thread's
-        // pixel addresses, the association's constants - is then recomputed per iteration instead of being hoisted out of the loop
-        // and kept in registers across the fp64 solve, which needs all 128 of a 1024-thread block for itself (hoisted, the solve
-        // spilled ~40 values inside its dependent chain: 252 B of scratch, "rows + solve" 10.5 k cycles instead of ~6 k).
-        asm volatile("" : "+s"(la.st), "+s"(la.inV), "+s"(la.inN), "+s"(la.refV), "+s"(la.refN), "+s"(la.result_map));
-        if (j + 1 == t.n_its) {       // the level's last iteration: its sums are the next launch's to solve
-            icp_track_block<false>(sh, la, blockIdx.x, t.part[it & 1]);
-            break;
-        }
-        icp_track_block<true>(sh, la, blockIdx.x, t.part[it & 1]);
-        ICP_STAMP(8 + 3 * j);
-        lean_grid_barrier(t.barrier, (unsigned)(j + 1) * a.nblocks, t.timeouts, t.timeout_ticks);
-        ICP_STAMP(9 + 3 * j);
-        icp_solve_rows_coherent(sh, a.st, t.part[it & 1], a.level, a.nblocks, a.icp_threshold, writer);
-        ICP_STAMP(10 + 3 * j);
-        run = sh.done[a.level] == 0;
-        if (writer) {
-            // records of the iterations that follow: the next one's (entered with this state, run or not), and - if the level is
-            // done - those of the rest, which would only have handed the state on
-            const int n_rec = run ? 1 : t.n_its - (j + 1);
-            if ((int)threadIdx.x < n_rec) {
-                IcpState &o = a.iters[it + 1 + (int)threadIdx.x];
-                o.pose = sh.pose;
-                for (int l = 0; l < KFH_MAX_LEVELS; ++l) o.done[l] = sh.done[l];
-                o.executed = run ? 1 : 0;
-            }
-        }
-    }
-}
-
-// all iterations of a coarse level in one launch (+ one side block that sorts a dispatch order, if asked for)
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_level(IcpIterArgs a, IcpLevelArgs t) {
-    __shared__ IcpShared sh;
-    __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.nblocks) { icp_level_block(sh, a, t); return; }
     ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode);
 }
 
@@ -1447,14 +1311,13 @@ struct SidePyramid {
 
 constexpr int SIDE_TEAMS = ICP_THREADS / 256;
 
-// LEVEL: the ICP blocks run every iteration of their level (k_icp_level's routine) instead of one; `lv` is read only then
-template <bool FD, bool LEVEL = false>
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bilateral(IcpIterArgs a, SideBilateral sb, IcpLevelArgs lv) {
+template <bool FD>
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bilateral(IcpIterArgs a, SideBilateral sb) {
     __shared__ IcpShared sh;
     __shared__ float tiles[SIDE_TEAMS][PBY + 2 * PR][PBX + 2 * PR + 1];
     __shared__ double exp_tab[32];
     __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.nblocks) { if (LEVEL) icp_level_block(sh, a, lv); else icp_iter_block(sh, a); return; }
+    if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // the raycast dispatch sort, if asked for, is the last block
     if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
@@ -1478,12 +1341,12 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
 #define KFH_PYR_SIDE_TEAMS 4
 #endif
 constexpr int PYR_SIDE_TEAMS = KFH_PYR_SIDE_TEAMS;      // tiles a side block of the pyramid job works on at a time (1, 2, 4)
-template <int NLEV, bool LEVEL = false>
-__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp, IcpLevelArgs lv) {
+template <int NLEV>
+__global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
     __shared__ IcpShared sh;
     __shared__ float lds[PYR_SIDE_TEAMS][pyr_lds_floats<NLEV>()];
     __shared__ RayOrderShared ro;
-    if (blockIdx.x < a.nblocks) { if (LEVEL) icp_level_block(sh, a, lv); else icp_iter_block(sh, a); return; }
+    if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
     if (order_blocks && blockIdx.x == gridDim.x - 1) { ray_order_block(ro, a.ray_order, a.ray_cost, a.ray_tiles_x, a.ray_tiles_y, a.order_mode); return; }
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
@@ -2668,25 +2531,10 @@ bool pyramid_fusable(int n_levels, unsigned W, unsigned H) {
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s,
-              int level_its, float *part0, float *part1) {
+              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s) {
     IcpIterArgs a = make_icp_args(st, iters, partials_prev, partials_out, result_map, it, level, prev_level, prev_nblocks,
                                         nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
                                         normal_threshold);
-    // level_its > 1: ONE launch for the iterations it .. it + level_its - 1 of this level (k_icp_level: one workgroup per block,
-    // lean grid barriers); the side work rides along as on a one-iteration launch
-    const bool whole_level = level_its > 1;
-    IcpLevelArgs lv;
-    lv.part[0] = part0; lv.part[1] = part1; lv.n_its = whole_level ? level_its : 1;
-    lv.barrier = &st->tail_barrier[level]; lv.timeouts = &st->barrier_timeouts;
-    {
-        static const long long ticks_env = [] { const char *e = getenv("KFH_ICP_TAIL_TIMEOUT_TICKS"); return e ? atoll(e) : -1LL; }();
-        lv.timeout_ticks = ticks_env >= 0 ? (unsigned long long)ticks_env : 200000000ull;
-    }
-    static WaveTrace lwt("KFH_ICP_LEVEL_TRACE");
-    static const int ltrace_it = [] { const char *e = getenv("KFH_ICP_TRACE_IT"); return e ? atoi(e) : 0; }();
-    const bool ltraced = whole_level && it == ltrace_it && (a.trace = lwt.arm(8, s)) != nullptr;
-    struct DumpAtExit { WaveTrace &w; bool on; ~DumpAtExit() { if (on) w.dump(); } } dump_at_exit{lwt, ltraced};
     if (side && side->kind == SideWork::BILATERAL && side->count) {
         SideBilateral sb;
         sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
@@ -2700,13 +2548,8 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
             extra = 1;
         }
         const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
-        if (whole_level) {
-            if (fd) k_icp_iter_bilateral<true, true><<<grid, ICP_THREADS, 0, s>>>(a, sb, lv);
-            else k_icp_iter_bilateral<false, true><<<grid, ICP_THREADS, 0, s>>>(a, sb, lv);
-        } else {
-            if (fd) k_icp_iter_bilateral<true, false><<<grid, ICP_THREADS, 0, s>>>(a, sb, lv);
-            else k_icp_iter_bilateral<false, false><<<grid, ICP_THREADS, 0, s>>>(a, sb, lv);
-        }
+        if (fd) k_icp_iter_bilateral<true><<<grid, ICP_THREADS, 0, s>>>(a, sb);
+        else k_icp_iter_bilateral<false><<<grid, ICP_THREADS, 0, s>>>(a, sb);
         launched("k_icp_iter_bilateral");
         return;
     }
@@ -2728,28 +2571,13 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
             extra = 1;
         }
         const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
-        if (whole_level) {
-            switch (side->n_levels) {
-            case 1: k_icp_iter_pyramid<1, true><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            case 2: k_icp_iter_pyramid<2, true><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            case 3: k_icp_iter_pyramid<3, true><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            default: k_icp_iter_pyramid<4, true><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            }
-        } else {
-            switch (side->n_levels) {
-            case 1: k_icp_iter_pyramid<1, false><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            case 2: k_icp_iter_pyramid<2, false><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            case 3: k_icp_iter_pyramid<3, false><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            default: k_icp_iter_pyramid<4, false><<<grid, ICP_THREADS, 0, s>>>(a, sp, lv); break;
-            }
+        switch (side->n_levels) {
+        case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 3: k_icp_iter_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        default: k_icp_iter_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
         }
         launched("k_icp_iter_pyramid");
-        return;
-    }
-    if (whole_level) {      // no tile work to carry: the level's blocks, plus one block for a dispatch sort if there is one to do
-        const bool order = side && side->kind == SideWork::RAY_ORDER;
-        if (order) { a.ray_order = side->ray_order; a.ray_cost = side->ray_cost; a.ray_tiles_x = side->ray_tiles_x; a.ray_tiles_y = side->ray_tiles_y; a.order_mode = side->order_mode; }
-        k_icp_level<<<nblocks + (order ? 1u : 0u), ICP_THREADS, 0, s>>>(a, lv); launched("k_icp_level");
         return;
     }
     static WaveTrace wt("KFH_ICP_TRACE");
@@ -2762,8 +2590,6 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
     }
     k_icp_iter<<<nblocks, ICP_THREADS, 0, s>>>(a); launched("k_icp_iter");
 }
-
-unsigned icp_level_max_blocks() { return 96; }
 
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,

@@ -73,7 +73,7 @@ struct kfh_context {
     unsigned seen_failed_frames = 0;
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
-    int barrier_cus = 0;               // CUs reserved on the device for this context's grid-barrier launches: 96 (k_icp_level + k_icp_tail), 32 (k_icp_tail only), 0 (neither: one launch per iteration); create_common, returned by kfh_destroy
+    bool barrier_slot = false;         // holds one of the device's eight k_icp_tail slots (create_common; returned by kfh_destroy)
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
@@ -137,8 +137,7 @@ struct kfh_context {
 // backends keep file-scope state, so kfh_synchronise_all() waits for all of them
 static std::mutex g_registry_mu;
 static std::vector<kfh_context *> g_registry;
-static std::map<int, int> g_barrier_budget;  // per device: CUs reserved by contexts for launches with a grid barrier (k_icp_level, k_icp_tail; guarded by g_registry_mu)
-static const int kBarrierCUs = 256, kWideCUs = 96, kNarrowCUs = 32;      // an MI355X has 256 CUs; a 1024-thread workgroup of these kernels fills one
+static std::map<int, int> g_barrier_slots;   // per device: contexts holding one of the eight co-residency slots of k_icp_tail (guarded by g_registry_mu)
 
 static hipEvent_t prof_event(kfh_context *c, int phase) {
     std::vector<hipEvent_t> &v = c->prof_events[phase];
@@ -342,21 +341,11 @@ static void fill_side_pyramid(const kfh_context *c, const NextFrameWork &nw, Sid
 // stops a level after 3 iterations in ~90 % of the frames: on level 1 (5 iterations) the tail then replaces the launch that finds
 // the level converged AND the one after it (cfg2 ICP loop 110.7 -> 108.5 us); on level 0 a third of a microsecond either way
 // (an iteration that does run inside the tail costs ~37 us there against ~14 on level 1), so its fourth iteration keeps its launch.
-static bool whole_level(const kfh_context *c, int level);
 static int tail_length(const kfh_context *c, int level) {
     const int n = c->iterations[level];
-    if (whole_level(c, level)) return 0;
     const int head = c->icp_tail_head.empty() ? (level == 0 ? 4 : 3) : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
     if (head <= 0 || n - head < 2) return 0;
     return n - head;
-}
-
-// Does this level run as ONE launch (k_icp_level)?  A coarse level of few blocks with at least two iterations, in a context that
-// holds the wide reservation; KFH_ICP_LEVEL=0 or an explicit KFH_ICP_TAIL_HEAD (the A/B switch of the older schedules) keep one
-// launch per iteration.
-static bool whole_level(const kfh_context *c, int level) {
-    if (level == 0 || c->barrier_cus < kWideCUs || !c->icp_tail_head.empty() || c->iterations[level] < 2) return false;
-    return launch::icp_blocks(level_dim(c->W, level), level_dim(c->H, level)) <= launch::icp_level_max_blocks();
 }
 
 // Queues the pyramid (unless `pyramid_ready`) and the whole ICP loop.  `end_ops` are the control operations that follow
@@ -388,12 +377,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     if (next) {
         static const std::vector<int> bil_env = parse_int_list(getenv("KFH_SIDE_BIL_ITS")), pyr_env = parse_int_list(getenv("KFH_SIDE_PYR_ITS"));
         const int first_l1 = c->iterations[L - 1] > 0 ? c->iterations[L - 1] : 0;    // first launch of the second-coarsest level
-        // first iterations of the two coarsest levels when these run as one launch each (k_icp_level): such a launch lasts a whole
-        // level, so ALL bilateral tiles ride on the coarsest level's and the pyramid (which needs the filtered depth complete) on the next
-        const bool lv_top = L >= 2 && whole_level(c, L - 1), lv_next = L >= 3 && whole_level(c, L - 2);
         if (!bil_env.empty() && (!next->pyramid || !pyr_env.empty())) { bil_its = bil_env; if (next->pyramid) pyr_its = pyr_env; }
-        else if (lv_top && (lv_next || L == 2) && first_l1 < coarse_launches) { bil_its = {0}; if (next->pyramid) pyr_its = {first_l1}; }
-        else if (lv_top && first_l1 + 1 < coarse_launches) { bil_its = {0}; if (next->pyramid) pyr_its = {first_l1 + 1}; }
         else if (next->pyramid) {
             if (coarse_launches >= 6 && first_l1 >= 4 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2, 3}; pyr_its = {first_l1 + 1}; }   // (1280x960: 233.7 -> 227.2 us per loop against two launches, 640x480 the same)
             else if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
@@ -404,14 +388,11 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
         // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
         bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
         int last = -1;
-        auto plain_launch = [&](int v) {    // a launch starts at iteration v (it is not folded into a level's tail or whole-level launch)
+        auto plain_launch = [&](int v) {    // iteration v has a launch of its own (is not folded into a level's tail launch)
             int first = 0;
             for (int level = L - 1; level >= 0; --level) {
                 const int n = c->iterations[level] > 0 ? c->iterations[level] : 0;
-                if (v < first + n) {
-                    if (whole_level(c, level)) return v == first;
-                    return tail_length(c, level) == 0 || v - first < n - tail_length(c, level);
-                }
+                if (v < first + n) return tail_length(c, level) == 0 || v - first < n - tail_length(c, level);
                 first += n;
             }
             return false;
@@ -431,8 +412,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     for (int level = L - 1; level >= 0; --level) {   // cpp:950-967
         const unsigned w = level_dim(c->W, level), h = level_dim(c->H, level);
         const unsigned nb = launch::icp_blocks(w, h);
-        const bool whole = whole_level(c, level);
-        const int n_tail = tail_length(c, level), n_plain = whole ? 1 : c->iterations[level] - n_tail;     // (a whole level is one launch)
+        const int n_tail = tail_length(c, level), n_plain = c->iterations[level] - n_tail;
         for (int i = 0; i < n_plain; ++i) {
             SideWork side;
             const SideWork *sp = nullptr;
@@ -471,11 +451,10 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                 side.ray_tiles_x = c->int_blocks; side.ray_tiles_y = 1;
                 c->int_order_stale = false;
             }
-            const int level_its = whole ? c->iterations[level] : 1;
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
-                             dist_threshold, normal_threshold, sp, c->stream, level_its, part[0], part[1]);
-            prev_level = level; prev_nb = nb; it += level_its;
+                             dist_threshold, normal_threshold, sp, c->stream);
+            prev_level = level; prev_nb = nb; ++it;
         }
         if (n_tail > 0) {   // the rarely needed late iterations of the level, one launch (k_icp_tail)
             static const bool fold_env = [] { const char *e = getenv("KFH_ICP_TAIL_CLOSES"); return !(e && e[0] == '0'); }();
@@ -729,20 +708,15 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float)));
     c->icp_tail_head = parse_int_list(getenv("KFH_ICP_TAIL_HEAD"));
     {
-        // Launches that synchronise their workgroups with a grid barrier need them resident together, whatever else runs: every
-        // context reserves the CUs its widest such launch occupies (a context runs one launch at a time) out of the device's 256 -
-        // 96 for k_icp_level (a coarse level's <= 96 blocks, one workgroup each) and k_icp_tail, 32 for k_icp_tail alone - so the
-        // first two contexts of a device get both, the next two the tail, and any further one gets one launch per iteration instead
-        // (no barrier, a few per cent slower) rather than a barrier that could time out.  Reserved HERE, under the registry lock (the
-        // context joins the registry only when it is complete), so concurrent kfh_create calls cannot overbook; kfh_destroy gives
-        // the reservation back, also for a creation that fails.
+        // k_icp_tail synchronises its <= 32 workgroups (one CU each) with a grid barrier: they must be resident together.  Eight
+        // such launches fit the 256 CUs at once whatever else runs, so up to eight contexts per device may use it; a ninth
+        // gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could time out.
+        // The slot is RESERVED here, under the registry lock (the context itself joins the registry only when it is complete): two
+        // threads creating contexts at once cannot both take the eighth.  kfh_destroy gives it back, also for a creation that fails.
         std::lock_guard<std::mutex> lk(g_registry_mu);
-        int &taken = g_barrier_budget[c->device];
-        static const bool level_env = [] { const char *e = getenv("KFH_ICP_LEVEL"); return !(e && e[0] == '0'); }();
-        if (level_env && taken + kWideCUs <= kBarrierCUs - 2 * kNarrowCUs) c->barrier_cus = kWideCUs;
-        else if (taken + kNarrowCUs <= kBarrierCUs) c->barrier_cus = kNarrowCUs;
-        else c->icp_tail_head.assign(1, 0);
-        taken += c->barrier_cus;
+        int &taken = g_barrier_slots[c->device];
+        if (taken >= 8) c->icp_tail_head.assign(1, 0);
+        else { ++taken; c->barrier_slot = true; }
     }
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
@@ -831,7 +805,7 @@ void kfh_destroy(kfh_context *c) {
         std::lock_guard<std::mutex> lk(g_registry_mu);
         for (size_t i = 0; i < g_registry.size(); ++i)
             if (g_registry[i] == c) { g_registry.erase(g_registry.begin() + i); break; }
-        if (c->barrier_cus) { g_barrier_budget[c->device] -= c->barrier_cus; c->barrier_cus = 0; }
+        if (c->barrier_slot) { --g_barrier_slots[c->device]; c->barrier_slot = false; }
     }
     hipSetDevice(c->device);
     c->pend.valid = false;   // a frame still deferred is dropped with the context
