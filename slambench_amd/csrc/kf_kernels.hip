@@ -1064,6 +1064,9 @@ __device__ __forceinline__ bool icp_enter(IcpShared &sh, const IcpIterArgs &a, i
 #ifndef KFH_ICP_LEAN
 #define KFH_ICP_LEAN 1
 #endif
+#ifndef KFH_ICP_BALANCE
+#define KFH_ICP_BALANCE 1      // remainder pixels of a level larger than one pass dealt to the blocks' waves (see icp_track_block)
+#endif
 struct AssocConsts { M4 T, view; int have_reference; unsigned refW; float wm1, hm1, dist_threshold, dist2_max, normal_threshold; };
 
 __device__ __forceinline__ int associate_accumulate(float (&acc)[32], float4 n4, float4 v4, const float4 *__restrict__ refV,
@@ -1124,7 +1127,7 @@ __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs
     // instead of three or four vector instructions per pixel and lane.
     unsigned cnt_in = 0, cnt_dist = 0, cnt_norm = 0, cnt_other = 0;
     const unsigned row_gap = a.refW - a.inW;     // the result map keeps the full-resolution row stride on every level (cpp:512)
-    for (unsigned p = vb * ICP_THREADS + threadIdx.x; p < n; p += a.nblocks * ICP_THREADS) {
+    auto one_pixel = [&](unsigned p) {
         // the input maps are dense (row stride inW): pixel (px, py) is element p
         float4 n4 = inN[p];
         float4 v4 = inV[p];
@@ -1140,6 +1143,23 @@ __device__ __forceinline__ void icp_track_block(IcpShared &sh, const IcpIterArgs
         cnt_dist += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result == -4));
         cnt_norm += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result == -5));
         cnt_other += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(result < 0 && result > -4));
+    };
+    // Which pixels a block owns.  A level of at most nblocks x 1024 pixels: block vb its 1024 consecutive ones.  A larger level
+    // (640x480: 300 groups of 1024 on 256 blocks) in full passes over all blocks - and the remainder, which is less than one pass, in
+    // 64-pixel chunks dealt round-robin to the blocks' WAVES (chunk c -> block c % nblocks, wave c / nblocks) instead of by whole
+    // groups to the first blocks: those then had two pixels on every thread - eight pixel-rows per SIMD where the others have four -
+    // and the launch waited for them; now a block has at most three waves with a second pixel, five rows on three of its SIMDs.
+    // The partition is part of the sum tree: it is the same for every schedule (launch per iteration, k_icp_tail's emulated blocks).
+    const unsigned stride = a.nblocks * ICP_THREADS;
+    const unsigned full = KFH_ICP_BALANCE ? n / stride : 0u;
+    if (full == 0) {
+        for (unsigned p = vb * ICP_THREADS + threadIdx.x; p < n; p += stride) one_pixel(p);
+    } else {
+        unsigned p = vb * ICP_THREADS + threadIdx.x;
+        for (unsigned k = 0; k < full; ++k, p += stride) one_pixel(p);
+        const unsigned chunk = vb + (threadIdx.x >> 6) * a.nblocks;
+        const unsigned pr = full * stride + chunk * 64u + (threadIdx.x & 63u);
+        if (pr < n) one_pixel(pr);
     }
     if ((threadIdx.x & 63) == 0) { acc[28] = (float)cnt_in; acc[29] = (float)cnt_dist; acc[30] = (float)cnt_norm; acc[31] = (float)cnt_other; }
 #else
