@@ -245,3 +245,42 @@ def test_fixed_schedule_emulation_of_the_references_openmp_reduction(orc):
     sixteen, again = run(16), run(16, omp=False)
     assert np.array_equal(sixteen[1].view(np.uint32), again[1].view(np.uint32))           # no dependence on the build or the host's threads
     assert np.abs(sixteen[0] - serial[0]).max() < 1e-5 and np.array_equal(sixteen[1][0, 28:], serial[1][0, 28:])   # counters are exact
+
+
+def test_squared_length_bound_of_the_icp_distance_test():
+    """The HIP association decides `length(diff) > dist_threshold` (cpp:543) on the squared length: sqrtf(d) > t  <=>  d > X with X the
+    largest float whose correctly rounded root is <= t (kf_math.h sqrt_gt_bound; on the device k_verify_sqrt_bound holds the device's
+    square root to it for all 2^31 non-negative floats).  This is the host-side construction restated in numpy float32: the bound
+    exists, sits where the rounded root crosses t, and agrees with the square root on a dense neighbourhood and on the special values."""
+    f32 = np.float32
+
+    def bound(t):
+        t = f32(t)
+        x = f32(t * t)
+        for _ in range(8):
+            if np.sqrt(x) > t:
+                x = np.nextafter(x, f32(-1))
+        for _ in range(8):
+            if np.sqrt(np.nextafter(x, f32(np.inf))) <= t:
+                x = np.nextafter(x, f32(np.inf))
+        assert np.sqrt(x) <= t < np.sqrt(np.nextafter(x, f32(np.inf)))
+        return x
+
+    rng = np.random.default_rng(7)
+    for t in [0.1, 0.0, 1e-20, 0.5, 1.0, 3.0000002, 1234.5678, 1e18] + list(rng.uniform(1e-3, 10.0, 200)):
+        x = bound(t)
+        t32 = f32(t)
+        # every float within 64 ulps of the bound, both sides
+        d = x.copy()
+        near = [x]
+        for _ in range(64):
+            d = np.nextafter(d, f32(np.inf)); near.append(d)
+        d = x.copy()
+        for _ in range(64):
+            if d > 0:
+                d = np.nextafter(d, f32(-1)); near.append(d)
+        near = np.array(near + [0.0, np.inf, np.nan, 1e-45, 3.4e38], dtype=f32)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(np.sqrt(near) > t32, near > x), t
+        wide = rng.uniform(0, 4 * float(x) + 1e-30, 2000).astype(f32)
+        assert np.array_equal(np.sqrt(wide) > t32, wide > x), t
