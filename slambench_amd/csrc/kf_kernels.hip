@@ -1467,9 +1467,6 @@ template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) 
 #ifndef KFH_INT_PROBE_NO_REPLAY
 #define KFH_INT_PROBE_NO_REPLAY 0
 #endif
-#ifndef KFH_INT_FREE_FAST
-#define KFH_INT_FREE_FAST 0      // measured slower (profiles/r04_sweeps.md): 42.0 -> 43.1 us at 256^3, 114.0 -> 117.7 at 512^3
-#endif
 #ifndef KFH_INT_IDLE_EXIT
 #define KFH_INT_IDLE_EXIT 1
 #endif
@@ -1657,31 +1654,6 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
-#if KFH_INT_FREE_FAST
-            // Free space in front of the surface, untouched so far: sdf = 1 (t >= mu) onto a stored 32766, which is 1.0f exactly
-            // (32766 * kShort2Float = 1), gives (w * 1 + 1) / (w + 1) = 1 -> 32766 again for every weight (checked for w = 0..100 on
-            // the host): only the weight moves, and once it is saturated nothing does.  Most updated voxels are of this kind, and
-            // with waves that own compact column patches a whole batch usually is: when EVERY lane's updates of the batch are
-            // (one ballot, no lane-level branch in the straight-line update code below) the division, the conversions and
-            // the clamps are skipped, and so is the store of a voxel that would not change.
-            {
-                bool plain = false;
-#pragma unroll
-                for (int i = 0; i < IB; ++i)
-                    if (need & (1u << i)) plain = plain || !(t_[i] >= mu) || c[i].x != (short)32766;
-                if (__builtin_amdgcn_ballot_w64(plain) == 0ull) {
-#pragma unroll
-                    for (int i = 0; i < IB; ++i) {
-                        if (!(need & (1u << i))) continue;
-                        const float w = c[i].y;
-                        const short wn = (short)fmin_h(w + 1, maxweight);
-                        if (wn != c[i].y) cell[(size_t)i * plane] = make_short2((short)32766, wn);
-                        ++updated;
-                    }
-                    continue;
-                }
-            }
-#endif
             // the world position of a band voxel is replayed from the batch's first state (3 packed adds per voxel) instead
             // of being kept in 24 registers across the two memory round trips above
             ColumnState R = first;
