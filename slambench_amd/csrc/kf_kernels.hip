@@ -1242,9 +1242,10 @@ __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned goal, u
     __syncthreads();
 }
 
-// The iterations of the launch that do run (rare): a routine of its own, NOT inlined, so that its set-up - loop invariants, spilled
-// addresses, the association's constants - cannot be hoisted in front of the verdict the usual case leaves with (as one loop the
-// kernel spent 7.4 k - 12.9 k cycles between entry and that verdict, depending on how the register allocation fell; 1.5 k now).
+// The iterations of the launch that do run (rare), AFTER the verdict the usual case leaves with: written as one loop with that
+// verdict inside it, the loop's set-up - its invariants, spilled addresses, the association's constants - was hoisted in front of
+// the first barrier and the kernel spent 7.4 k - 12.9 k cycles between entry and the verdict, depending on how the register
+// allocation fell; 1.5 k now.  (Inlined: as a called routine its two argument structures were copied to scratch at the kernel's top.)
 // Enters with the state of iteration a.it in `sh` and that iteration due.  Returns true if the caller (the writer workgroup of a
 // closing launch) is to close the frame's ICP loop.
 __device__ __forceinline__ bool icp_tail_iterations(IcpShared &sh, const IcpIterArgs &a, const IcpTailArgs &t) {
