@@ -9,4 +9,4 @@ export TMPDIR=/tmp
 mkdir -p "$out"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers --no-measure-traffic --no-preheat "$@" > "$out/fetch.json" 2> "$out/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-total --no-host-buffers --no-measure-traffic --no-preheat "$@" > "$out/write.json" 2> "$out/write.err"
-python3 profiles/summarise_traffic.py "$out"
+python3 profiles/summarise_traffic.py "$out" 50      # 40 + 10 frames of one context

@@ -23,7 +23,9 @@ def per_kernel(dirname, counter):
     return acc
 
 
-def main(out):
+def main(out, frames=None):
+    """frames: frames of the profiled run (steps + warm-up of its one context), written into the summary: bench.py divides the ICP
+    loop's bytes by it (without it by the launches of k_raycast, which is a few per cent high)"""
     fetch = per_kernel(out + "/fetch", "FETCH_SIZE")
     write = per_kernel(out + "/write", "WRITE_SIZE")
     res = {}
@@ -44,11 +46,15 @@ def main(out):
             # and divides by the frames of the run, i.e. the launches of k_raycast)
             "hbm_bytes_total": round((2 * sum(f) + sum(w)) * 1024),
         }
+    if frames:
+        res["frames"] = int(frames)
     json.dump(res, open(out + "/traffic.json", "w"), indent=1)
     for k, v in res.items():
+        if not isinstance(v, dict):
+            continue
         print("%-34s launches %5d  fetch %10.1f KiB (x2 corrected %10.1f)  write %10.1f KiB  -> %12d B/launch" %
               (k[:34], v["launches"], v["fetch_kib_raw"], 2 * v["fetch_kib_raw"], v["write_kib"], v["hbm_bytes_per_launch"]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else None)
