@@ -284,3 +284,19 @@ def test_squared_length_bound_of_the_icp_distance_test():
             assert np.array_equal(np.sqrt(near) > t32, near > x), t
         wide = rng.uniform(0, 4 * float(x) + 1e-30, 2000).astype(f32)
         assert np.array_equal(np.sqrt(wide) > t32, wide > x), t
+
+
+def test_row_of_a_pixel_by_a_reciprocal_multiplication():
+    """The HIP ICP association needs the row of pixel p on a coarse level (the result map keeps the full-resolution row stride,
+    cpp:512) and computes it as (unsigned)(((float)p + 0.5f) * RN(1 / inW)) while the level has at most 2^22 pixels
+    (kf_kernels.hip make_icp_args / icp_track_block), instead of an integer division by a run-time value.  The same float32
+    operations in numpy, for EVERY pixel below 2^22 of widths of every kind (powers of two, odd, prime, the pyramid levels of the
+    benchmark sizes): equal to p // inW."""
+    f32 = np.float32
+    p = np.arange(1 << 22, dtype=np.uint32)
+    pf = p.astype(f32) + f32(0.5)
+    for w in (1, 2, 3, 7, 36, 45, 50, 75, 80, 90, 100, 113, 125, 150, 160, 161, 250, 320, 333, 500, 640, 641, 1000, 1023, 1024, 1280, 1920, 2047, 4093):
+        inv = f32(1.0) / f32(w)
+        n = min(1 << 22, w * 4096)
+        rows = (pf[:n] * inv).astype(np.uint32)
+        assert np.array_equal(rows, p[:n] // np.uint32(w)), w
