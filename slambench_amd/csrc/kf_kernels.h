@@ -107,6 +107,7 @@ struct SideWork {
     float e_d;                        // e_delta for BILATERAL, e_delta * 3 for PYRAMID
     // PYRAMID (cpp:931-945)
     int n_levels;
+    int pyr_part;                     // 0: every level of the tiles; 1: level 0 only; 2: the levels above it
     float *scaled[4];
     float4 *vertex[4], *normal[4];
     const float4 *stale_normal[4];
@@ -126,6 +127,7 @@ const char *take_launch_error();
 unsigned track_blocks(unsigned w, unsigned h);
 unsigned bilateral_tiles(unsigned W, unsigned H);
 unsigned pyramid_tiles(unsigned W, unsigned H);
+unsigned pyramid_side_rounds(unsigned tiles, unsigned icp_nb);
 bool pyramid_fusable(int n_levels, unsigned W, unsigned H);
 unsigned track_blocks_max();
 unsigned icp_blocks(unsigned w, unsigned h);

@@ -120,14 +120,25 @@ __device__ __forceinline__ void bilateral_block(float (*tile)[PBX + 2 * PR + 1],
     const int x0 = bx * PBX, y0 = by * PBY;
     constexpr int TW = PBX + 2 * PR, TH = PBY + 2 * PR;
     if (active) {
-        for (int idx = tid; idx < TW * TH; idx += PBX * PBY) {
-            const int ty = idx / TW, tx = idx - ty * TW;
-            const int gx = imax(0, imin(x0 + tx - PR, (int)W - 1));
-            const int gy = imax(0, imin(y0 + ty - PR, (int)H - 1));
-            float v;
-            if (FROM_MM) v = static_cast<const uint16_t *>(inv)[gx * ratio + inW * gy * ratio] / 1000.0f;
-            else v = static_cast<const float *>(inv)[gx + gy * W];
-            tile[ty][tx] = v;
+        // every load of the tile is issued before the first is waited for (a cold miss takes ~1 us, and a loop of
+        // load - store - load would pay it once per round)
+        constexpr int ROUNDS = (TW * TH + PBX * PBY - 1) / (PBX * PBY);
+        float v[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = tid + r * PBX * PBY;
+            if (idx < TW * TH) {
+                const int ty = idx / TW, tx = idx - ty * TW;
+                const int gx = imax(0, imin(x0 + tx - PR, (int)W - 1));
+                const int gy = imax(0, imin(y0 + ty - PR, (int)H - 1));
+                if (FROM_MM) v[r] = static_cast<const uint16_t *>(inv)[gx * ratio + inW * gy * ratio] / 1000.0f;
+                else v[r] = static_cast<const float *>(inv)[gx + gy * W];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = tid + r * PBX * PBY;
+            if (idx < TW * TH) { const int ty = idx / TW; tile[ty][idx - ty * TW] = v[r]; }
         }
     }
     __syncthreads();
@@ -292,6 +303,7 @@ struct PyramidArgs {
     M4 invK[PYR_MAX_LEVELS];
     unsigned W, H;
     float e_d;
+    bool through;       // the maps' stores go through L2 as they are issued (store_through)
 };
 constexpr int PYR_THREADS = 256;
 
@@ -309,6 +321,18 @@ struct PyrGeom {
     static constexpr int count = pyr_count(NLEV, L);
     static constexpr int offset = pyr_offset(NLEV, L);
 };
+
+// A 16-byte store that, if `through`, goes through the XCD's L2 to memory as it is issued (`sc0 sc1`) instead of staying
+// there dirty until the launch's closing write-back.  Worth it where a side block stores one
+// tile's maps and ends (640x480: the launch that carries the upper levels 8.65 -> 8.15 us); where a block works through nine
+// rounds of tiles (1280x960) the stores of one round drain while the next computes, and going through costs +2.3 us a launch
+// (profiles/r04_ab_pyr_wt.txt).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_through(bool through, float4 *p, float x, float y, float z, float w) {
+    // (as an instruction, not a volatile access: the compiler would wait for each of those before issuing the next)
+    if (through) { const v4f_t v{x, y, z, w}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory"); }    // (s_nop: the data registers may be rewritten next)
+    else *p = make_float4(x, y, z, w);
+}
 
 template <int NLEV, int L, int NTHR>
 __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
@@ -341,38 +365,78 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
         }
         __syncthreads();
     }
-    // vertex and normal maps of the tile (cpp:206-215, 225-247)
+    // vertex and normal maps of the tile (cpp:206-215, 225-247).  Three passes over the thread's pixels (four on level 0, one or
+    // none above it) so that the loads of the stale normals - a cold miss each, wherever a wave holds an invalid pixel - are all in
+    // flight together instead of one per round; the arithmetic is store_normal's.
     const M4 invK = a.invK[L];
-    for (int idx = tid; idx < G::tile * G::tile; idx += NTHR) {
+    constexpr int N = G::tile * G::tile, ROUNDS = (N + NTHR - 1) / NTHR;
+    f3 vc[ROUNDS], vn[ROUNDS];
+    size_t where[ROUNDS];
+    bool on[ROUNDS], bad[ROUNDS];
+    const float4 *stale = a.stale_normal[L];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int idx = tid + r * NTHR;
         const int ty = idx / G::tile, tx = idx - ty * G::tile;
         const int x = X0 + tx, y = Y0 + ty;
-        if (x >= (int)Wl || y >= (int)Hl) continue;
+        on[r] = idx < N && x < (int)Wl && y < (int)Hl;
+        bad[r] = false;
+        if (!on[r]) continue;
+        where[r] = x + (size_t)y * Wl;
         const int xl = imax(x - 1, 0), xr = imin(x + 1, (int)Wl - 1), yu = imax(y - 1, 0), yd = imin(y + 1, (int)Hl - 1);
         const int ox = X0 - G::halo, oy = Y0 - G::halo;
-        const f3 c = back_project(d[(y - oy) * G::stride + (x - ox)], x, y, invK);
+        vc[r] = back_project(d[(y - oy) * G::stride + (x - ox)], x, y, invK);
         const f3 l = back_project(d[(y - oy) * G::stride + (xl - ox)], xl, y, invK);
-        const f3 r = back_project(d[(y - oy) * G::stride + (xr - ox)], xr, y, invK);
+        const f3 rt = back_project(d[(y - oy) * G::stride + (xr - ox)], xr, y, invK);
         const f3 u = back_project(d[(yu - oy) * G::stride + (x - ox)], x, yu, invK);
         const f3 dn = back_project(d[(yd - oy) * G::stride + (x - ox)], x, yd, invK);
-        a.vertex[L][x + (size_t)y * Wl] = make_float4(c.x, c.y, c.z, 0.f);
-        store_normal(a.normal[L] + x + (size_t)y * Wl, l, r, u, dn, a.stale_normal[L] ? a.stale_normal[L] + x + (size_t)y * Wl : nullptr);
+        bad[r] = l.z == 0 || rt.z == 0 || u.z == 0 || dn.z == 0;
+        if (!bad[r]) vn[r] = normalize3(cross3(sub3(dn, u), sub3(rt, l)));
     }
+    float4 old[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (on[r] && bad[r] && stale) old[r] = stale[where[r]];
+    // store_through's instruction is invisible to the compiler's count of outstanding memory operations, and a store may retire
+    // before an older load: a `vmcnt(n)` computed for a load would be met early by it.  So nothing of the compiler's is in flight
+    // when the first of them is issued, and none of them when the compiler's next load is.
+    if (a.through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (!on[r]) continue;
+        store_through(a.through, a.vertex[L] + where[r], vc[r].x, vc[r].y, vc[r].z, 0.f);
+        float4 *out = a.normal[L] + where[r];
+        if (!bad[r]) store_through(a.through, out, vn[r].x, vn[r].y, vn[r].z, 0.f);
+        else if (stale) store_through(a.through, out, kInvalid, old[r].y, old[r].z, old[r].w);      // SURVEY N3, as store_normal
+        else reinterpret_cast<float *>(out)[0] = kInvalid;
+    }
+    if (a.through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// One 32x32 level-0 tile by the NTHR threads of a block.
-template <int NLEV, int NTHR>
+// One 32x32 level-0 tile by the NTHR threads of a block.  UPPER_ONLY: the maps of level 0 are somebody else's (a
+// pyramid_block<1> over the same tile, in another launch); the level-0 depth is still staged, the levels above come from it.
+template <int NLEV, int NTHR, bool UPPER_ONLY = false>
 __device__ __forceinline__ void pyramid_block(const PyramidArgs &a, float *lds, int bx, int by, int tid) {
     using G0 = PyrGeom<NLEV, 0>;
     // level-0 tile with halo; taps outside the image take the nearest pixel (only the 1-pixel ring is ever read there,
     // by the clamped neighbour accesses of the normals)
     const int X0 = bx * PYR_T - G0::halo, Y0 = by * PYR_T - G0::halo;
-    for (int idx = tid; idx < G0::count; idx += NTHR) {
-        const int ly = idx / G0::stride, lx = idx - ly * G0::stride;
-        const int gx = imax(0, imin(X0 + lx, (int)a.W - 1)), gy = imax(0, imin(Y0 + ly, (int)a.H - 1));
-        lds[idx] = a.scaled[0][gx + (size_t)gy * a.W];
+    constexpr int ROUNDS = (G0::count + NTHR - 1) / NTHR;      // all loads in flight before the first LDS store (see bilateral_block)
+    float v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int idx = tid + r * NTHR;
+        if (idx < G0::count) {
+            const int ly = idx / G0::stride, lx = idx - ly * G0::stride;
+            const int gx = imax(0, imin(X0 + lx, (int)a.W - 1)), gy = imax(0, imin(Y0 + ly, (int)a.H - 1));
+            v[r] = a.scaled[0][gx + (size_t)gy * a.W];
+        }
     }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (tid + r * NTHR < G0::count) lds[tid + r * NTHR] = v[r];
     __syncthreads();
-    pyramid_level<NLEV, 0, NTHR>(a, lds, bx, by, tid);
+    if constexpr (!UPPER_ONLY) pyramid_level<NLEV, 0, NTHR>(a, lds, bx, by, tid);
     if constexpr (NLEV > 1) pyramid_level<NLEV, 1, NTHR>(a, lds, bx, by, tid);
     if constexpr (NLEV > 2) pyramid_level<NLEV, 2, NTHR>(a, lds, bx, by, tid);
     if constexpr (NLEV > 3) pyramid_level<NLEV, 3, NTHR>(a, lds, bx, by, tid);
@@ -1362,10 +1426,15 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_bi
 #define KFH_PYR_SIDE_TEAMS 4
 #endif
 constexpr int PYR_SIDE_TEAMS = KFH_PYR_SIDE_TEAMS;      // tiles a side block of the pyramid job works on at a time (1, 2, 4)
-template <int NLEV>
+// PART 0: the whole pyramid of a tile; 1: level 0 only (the geometry of a one-level pyramid: a 1-pixel halo); 2: the levels above
+// it.  A tile's chain - cold tile load, level 0's maps, then a barrier and a pass per coarser level - is what the launch waits
+// for (11.6 us against 7.3 us for the iteration alone at 640x480, 28 against 10 at 1280x960); cut in two it hides behind two
+// iterations.  Parts 1 and 2 read the same filtered depth and write different maps, in either order.
+template <int NLEV, int PART, int TEAMS = PYR_SIDE_TEAMS>
 __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_pyramid(IcpIterArgs a, SidePyramid sp) {
+    constexpr int GEOM = PART == 1 ? 1 : NLEV;
     __shared__ IcpShared sh;
-    __shared__ float lds[PYR_SIDE_TEAMS][pyr_lds_floats<NLEV>()];
+    __shared__ float lds[TEAMS][pyr_lds_floats<GEOM>()];
     __shared__ RayOrderShared ro;
     if (blockIdx.x < a.nblocks) { icp_iter_block(sh, a); return; }
     const unsigned order_blocks = a.ray_order ? 1u : 0u;     // a dispatch sort, if asked for, is the last block
@@ -1373,19 +1442,19 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_iter_py
     const unsigned side = blockIdx.x - a.nblocks, nside = gridDim.x - a.nblocks - order_blocks;
     const unsigned tiles_x = (sp.a.W + PYR_T - 1) / PYR_T;
     // A tile is a chain of barriers (load, then level by level) that lasts ~7 us however many threads work on it, so the block
-    // runs PYR_SIDE_TEAMS tiles at a time, each by a team of the size the stand-alone kernel's blocks have (same routine, same
+    // runs TEAMS tiles at a time, each by a team of the size the stand-alone kernel's blocks have (same routine, same
     // bits), instead of one tile by all 1024 threads (the launch that carries the pyramid at 1280x960: 39.5 -> 29 us; eight teams: 27 us there but
     // +7 us at 640x480, profiles/r02_sweeps.md).  Tile i of the range goes to block
     // i % nside, team (i / nside) % TEAMS; a team without a tile runs the routine on a tile position right of the image,
     // which passes every barrier and writes nothing.
-    constexpr int TEAM_THREADS = ICP_THREADS / PYR_SIDE_TEAMS;
+    constexpr int TEAM_THREADS = ICP_THREADS / TEAMS;
     const int team = (int)threadIdx.x / TEAM_THREADS, tid = (int)threadIdx.x % TEAM_THREADS;
-    const unsigned rounds = (sp.count + nside * PYR_SIDE_TEAMS - 1) / (nside * PYR_SIDE_TEAMS);
+    const unsigned rounds = (sp.count + nside * TEAMS - 1) / (nside * TEAMS);
     for (unsigned r = 0; r < rounds; ++r) {
-        const unsigned i = (r * PYR_SIDE_TEAMS + (unsigned)team) * nside + side;
+        const unsigned i = (r * TEAMS + (unsigned)team) * nside + side;
         const unsigned t = sp.first + i;
         const bool active = i < sp.count;
-        pyramid_block<NLEV, TEAM_THREADS>(sp.a, lds[team], active ? (int)(t % tiles_x) : (int)tiles_x, active ? (int)(t / tiles_x) : 0, tid);
+        pyramid_block<GEOM, TEAM_THREADS, PART == 2>(sp.a, lds[team], active ? (int)(t % tiles_x) : (int)tiles_x, active ? (int)(t / tiles_x) : 0, tid);
         __syncthreads();
     }
 }
@@ -2456,7 +2525,7 @@ bool pyramid(int n_levels, float *const *scaled, float4 *const *vertex, float4 *
         a.stale_normal[l] = (l < n_levels && stale_normal) ? stale_normal[l] : nullptr;
         a.invK[l] = l < n_levels ? invK[l] : identity4();
     }
-    a.W = W; a.H = H; a.e_d = e_d;
+    a.W = W; a.H = H; a.e_d = e_d; a.through = false;
     const dim3 grid((W + PYR_T - 1) / PYR_T, (H + PYR_T - 1) / PYR_T);
     switch (n_levels) {
     case 1: k_pyramid<1><<<grid, 256, 0, s>>>(a); launched("k_pyramid"); break;
@@ -2515,6 +2584,11 @@ static unsigned side_blocks(unsigned tiles, unsigned icp_nb) {
     return tiles < room ? (tiles ? tiles : 1) : room;
 }
 
+// rounds of tiles a side block of a launch with `icp_nb` ICP blocks works through for `tiles` pyramid tiles
+unsigned pyramid_side_rounds(unsigned tiles, unsigned icp_nb) {
+    const unsigned slots = side_blocks(tiles, icp_nb + 1) * PYR_SIDE_TEAMS;
+    return (tiles + slots - 1) / slots;
+}
 unsigned bilateral_tiles(unsigned W, unsigned H) { return ((W + PBX - 1) / PBX) * ((H + PBY - 1) / PBY); }
 unsigned pyramid_tiles(unsigned W, unsigned H) { return ((W + PYR_T - 1) / PYR_T) * ((H + PYR_T - 1) / PYR_T); }
 bool pyramid_fusable(int n_levels, unsigned W, unsigned H) {
@@ -2557,6 +2631,8 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
             sp.a.invK[l] = on ? side->invK[l] : identity4();
         }
         sp.a.W = side->W; sp.a.H = side->H; sp.a.e_d = side->e_d;
+        static const int through_env = [] { const char *e = getenv("KFH_PYR_THROUGH"); return e ? atoi(e) : -1; }();     // 0 / 1: never / always
+        sp.a.through = through_env >= 0 ? through_env == 1 : pyramid_side_rounds(side->count, nblocks) == 1;
         sp.first = side->first; sp.count = side->count;
         unsigned extra = 0;
         if (side->ray_order) {   // a dispatch sort shares the launch
@@ -2564,11 +2640,21 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
             extra = 1;
         }
         const unsigned grid = nblocks + side_blocks(side->count, nblocks + extra) + extra;
-        switch (side->n_levels) {
-        case 1: k_icp_iter_pyramid<1><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 2: k_icp_iter_pyramid<2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        case 3: k_icp_iter_pyramid<3><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
-        default: k_icp_iter_pyramid<4><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        const int part = side->n_levels >= 2 ? side->pyr_part : 0;
+        // level 0 alone: four pixels a thread with teams of 256; with teams of 512, if the side blocks still take all tiles in one
+        // round, two (640x480: the launch 9.0 -> 8.65 us, profiles/r04_pyr_teams.txt)
+        if (part == 1 && PYR_SIDE_TEAMS > 2 && side->count <= 2 * side_blocks(side->count, nblocks + extra)) k_icp_iter_pyramid<1, 1, 2><<<grid, ICP_THREADS, 0, s>>>(a, sp);
+        else if (part == 1) k_icp_iter_pyramid<1, 1><<<grid, ICP_THREADS, 0, s>>>(a, sp);
+        else if (part == 2) switch (side->n_levels) {
+        case 2: k_icp_iter_pyramid<2, 2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 3: k_icp_iter_pyramid<3, 2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        default: k_icp_iter_pyramid<4, 2><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        }
+        else switch (side->n_levels) {
+        case 1: k_icp_iter_pyramid<1, 0><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 2: k_icp_iter_pyramid<2, 0><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        case 3: k_icp_iter_pyramid<3, 0><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
+        default: k_icp_iter_pyramid<4, 0><<<grid, ICP_THREADS, 0, s>>>(a, sp); break;
         }
         launched("k_icp_iter_pyramid");
         return;

@@ -374,20 +374,11 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
     int coarse_launches = 0;
     for (int level = L - 1; level >= 1; --level) coarse_launches += c->iterations[level] > 0 ? c->iterations[level] : 0;
     std::vector<int> bil_its, pyr_its;
+    bool pyr_by_level = false;      // two pyramid launches: level 0 on the first, the levels above it on the second (else: half the tiles each)
     if (next) {
         static const std::vector<int> bil_env = parse_int_list(getenv("KFH_SIDE_BIL_ITS")), pyr_env = parse_int_list(getenv("KFH_SIDE_PYR_ITS"));
+        static const int split_env = [] { const char *e = getenv("KFH_PYR_SPLIT"); return e ? atoi(e) : 1; }();     // 0: one launch; 1: by level
         const int first_l1 = c->iterations[L - 1] > 0 ? c->iterations[L - 1] : 0;    // first launch of the second-coarsest level
-        if (!bil_env.empty() && (!next->pyramid || !pyr_env.empty())) { bil_its = bil_env; if (next->pyramid) pyr_its = pyr_env; }
-        else if (next->pyramid) {
-            if (coarse_launches >= 6 && first_l1 >= 4 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2, 3}; pyr_its = {first_l1 + 1}; }   // (1280x960: 233.7 -> 227.2 us per loop against two launches, 640x480 the same)
-            else if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
-            else if (coarse_launches >= 3) { bil_its = {0, 1}; pyr_its = {2}; }
-            else if (coarse_launches == 2) { bil_its = {0}; pyr_its = {1}; }
-        } else if (coarse_launches >= 3) bil_its = {1, 2};
-        else if (coarse_launches >= 1) bil_its = {0};
-        // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
-        bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
-        int last = -1;
         auto plain_launch = [&](int v) {    // iteration v has a launch of its own (is not folded into a level's tail launch)
             int first = 0;
             for (int level = L - 1; level >= 0; --level) {
@@ -397,6 +388,31 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             }
             return false;
         };
+        if (!bil_env.empty() && (!next->pyramid || !pyr_env.empty())) { bil_its = bil_env; if (next->pyramid) pyr_its = pyr_env; pyr_by_level = split_env == 1 && pyr_its.size() == 2; }
+        else if (next->pyramid) {
+            if (coarse_launches >= 6 && first_l1 >= 4 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2, 3}; pyr_its = {first_l1 + 1}; }   // (1280x960: 233.7 -> 227.2 us per loop against two launches, 640x480 the same)
+            else if (coarse_launches >= 6 && first_l1 >= 3 && first_l1 + 1 < coarse_launches) { bil_its = {1, 2}; pyr_its = {first_l1 + 1}; }
+            else if (coarse_launches >= 3) { bil_its = {0, 1}; pyr_its = {2}; }
+            else if (coarse_launches == 2) { bil_its = {0}; pyr_its = {1}; }
+            // Level 0 on that launch and the levels above it on the next, if that one exists on its own (it is an iteration that nearly
+            // always runs) and a side block has one tile to do: the chain of a tile (load, level 0's maps and their write-back, then
+            // a barrier and a pass per coarser level) is what the carrying launch waits for, and cut in two it hides better
+            // (640x480: 11.4 + 7.2 us for the two launches -> 9.8 + 8.2).  Where the side blocks work through rounds of tiles
+            // (1280x960: 32 side blocks, nine rounds) the second load of the tiles costs what the split saves (profiles/r04_pyr_split.txt).
+            if (split_env == 1 && L >= 2 && !pyr_its.empty() && pyr_its[0] + 1 < coarse_launches && plain_launch(pyr_its[0] + 1)) {
+                int first = 0, level = L - 1;
+                for (; level >= 1; --level) { const int n = c->iterations[level] > 0 ? c->iterations[level] : 0; if (pyr_its[0] < first + n) break; first += n; }
+                const unsigned nb = launch::icp_blocks(level_dim(c->W, level), level_dim(c->H, level));
+                if (launch::pyramid_side_rounds(launch::pyramid_tiles(c->W, c->H), nb) == 1) {
+                    pyr_its.push_back(pyr_its[0] + 1);
+                    pyr_by_level = true;
+                }
+            }
+        } else if (coarse_launches >= 3) bil_its = {1, 2};
+        else if (coarse_launches >= 1) bil_its = {0};
+        // sanity: ascending, inside the coarse launches, every pyramid launch after every bilateral one
+        bool ok = !bil_its.empty() && (!next->pyramid || !pyr_its.empty());
+        int last = -1;
         for (int v : bil_its) { ok = ok && v > last && v < coarse_launches && plain_launch(v); last = v; }
         for (int v : pyr_its) { ok = ok && v > last && v < coarse_launches && plain_launch(v); last = v; }
         if (!ok) { bil_its.clear(); pyr_its.clear(); }
@@ -424,8 +440,10 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
                 }
             for (size_t j = 0; placed && j < pyr_its.size(); ++j)
                 if (pyr_its[j] == it) {
-                    const unsigned lo = (unsigned)((unsigned long long)pyr_tiles * j / pyr_its.size()), hi = (unsigned)((unsigned long long)pyr_tiles * (j + 1) / pyr_its.size());
+                    const unsigned lo = pyr_by_level ? 0u : (unsigned)((unsigned long long)pyr_tiles * j / pyr_its.size());
+                    const unsigned hi = pyr_by_level ? pyr_tiles : (unsigned)((unsigned long long)pyr_tiles * (j + 1) / pyr_its.size());
                     fill_side_pyramid(c, *next, side, lo, hi - lo);
+                    if (pyr_by_level) side.pyr_part = (int)j + 1;
                     sp = &side;
                 }
             // The two dispatch sorts (one block each; raycast tiles ~10 us, integrate blocks ~5.5 us) ride on side launches

@@ -221,6 +221,7 @@ def test_ray_march_variants_agree(hip, tmp_path):
                 {"KFH_RAY_GROUP": "4", "KFH_RAY_REORDER": "0"}, {"KFH_RAY_GROUP": "4", "KFH_EXACT_DIV": "0"},
                 {"KFH_RAY_GROUP": "4", "KFH_PIPELINE": "0"}, {"KFH_RAY_GROUP": "1"},
                 {"KFH_ICP_TAIL_HEAD": "0", "KFH_INTEGRATE_REORDER": "0"}, {"KFH_EXACT_SQRT": "0", "KFH_ICP_TAIL_HEAD": "4,4,4"}, {"KFH_ICP_TAIL_CLOSES": "0", "KFH_SIDE_BIL_ITS": "0,1", "KFH_SIDE_PYR_ITS": "2"},
+                {"KFH_PYR_SPLIT": "0"}, {"KFH_PYR_SPLIT": "2", "KFH_SIDE_BIL_ITS": "1,2", "KFH_SIDE_PYR_ITS": "4,5"},
                 {"KFH_INTEGRATE_BATCH": "4", "KFH_INTEGRATE_CHUNKS": "16"}, {"KFH_INTEGRATE_BATCH": "16", "KFH_INTEGRATE_CHUNKS": "2"})
     for i, env in enumerate(variants):
         out = str(tmp_path / ("v_%d.npz" % i))
