@@ -1537,6 +1537,9 @@ template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) 
 #ifndef KFH_INT_PROBE_NO_REPLAY
 #define KFH_INT_PROBE_NO_REPLAY 0
 #endif
+#ifndef KFH_INT_SPECULATE
+#define KFH_INT_SPECULATE 0
+#endif
 #ifndef KFH_INT_IDLE_EXIT
 #define KFH_INT_IDLE_EXIT 1
 #endif
@@ -1701,9 +1704,18 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             ++work;
             if (!live || (dbg & 2)) continue;
             float d[IB];
+#if KFH_INT_SPECULATE
+            // the voxels are requested WITH the depths that decide whether they are needed (one memory round trip per batch
+            // instead of two in a row; the voxels behind the surface are fetched for nothing)
+            short2 c[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                if (live & (1u << i)) { d[i] = depth[pix[i]]; c[i] = cell[(size_t)i * plane]; }
+#else
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (live & (1u << i)) d[i] = depth[pix[i]];
+#endif
             // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
             unsigned need = 0;
             float t_[IB];
@@ -1720,10 +1732,12 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             if (!need || (dbg & 4)) continue;
             work += 4;
+#if !KFH_INT_SPECULATE
             short2 c[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
+#endif
             // the world position of a band voxel is replayed from the batch's first state (3 packed adds per voxel) instead
             // of being kept in 24 registers across the two memory round trips above
             ColumnState R = first;
