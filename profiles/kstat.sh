@@ -30,7 +30,12 @@ frames = len(d.get([k for k in d if "raycast" in k][0], [])) if any("raycast" in
 frames = max(1, frames - frames // 3)
 print("%-44s fps %7.1f | %s | icp loop %.1f us/frame" % (sys.argv[2], fps, " | ".join(parts), icp / frames))
 # per ICP kernel: steady average (rocprofv3's duration of a launch in a dependent chain includes its launch boundary)
+def med(v):
+    v = sorted(v[len(v) // 3:])
+    return v[len(v) // 2] if v else float("nan")
 print("    " + "  ".join("%s %.2f (x%.1f)" % (k.split("<")[0].replace("k_icp_", ""), steady(v), (len(v) - len(v) // 3) / frames) for k, v in sorted(d.items()) if "icp" in k))
+if "KSTAT_MEDIANS" in __import__("os").environ:
+    print("    medians: " + "  ".join("%s %.2f" % (k.replace("kf::", "").replace("k_icp_", "").split("(")[0], med(v)) for k, v in sorted(d.items()) if "icp" in k))
 PY
   rm -rf $out $out.json $out.err
 done

@@ -1282,6 +1282,9 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
 constexpr unsigned ICP_TAIL_BLOCKS = 32;
+#ifndef KFH_TAIL_PROBE_NO_RARE
+#define KFH_TAIL_PROBE_NO_RARE 0
+#endif
 
 struct IcpTailArgs {
     float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
@@ -1365,7 +1368,11 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
         }
         ICP_STAMP(2);
     } else {
+#if KFH_TAIL_PROBE_NO_RARE      // timing probe only (results are wrong whenever a late iteration is due): what the scratch the loop declares costs the usual path
+        close = closes && writer;
+#else
         close = icp_tail_iterations(sh, a, t);
+#endif
     }
     // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
     if (close) close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
