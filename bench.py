@@ -57,9 +57,10 @@ MU, ICP_THRESHOLD, TRACKING_RATE = 0.1, float(os.environ.get("KFH_DEBUG_ICP_THRE
 V_FRAMES = 2            # frames after the cpu_baseline prefix on which the oracle counts V (distinct voxels a raycast samples)
 
 
-def icp_launches(pyramid, heads=(4, 3)):
-    """launches of a frame's ICP loop: per level the first `head` iterations one each (4 on level 0, 3 on the coarser ones), the
-    rest (if >= 2) share one (kf_pipeline.hip tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
+def icp_launches(pyramid, heads=(3, 3)):
+    """launches of a frame's ICP loop: per level the first `head` iterations one each (3 for the first context of a device, whose
+    shared launch is 64 workgroups wide; 4 on level 0 for further contexts), the rest (if >= 2) share one (kf_pipeline.hip
+    tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
     n, closed = 0, False
     for level, its in enumerate(pyramid):
         head = heads[min(level, len(heads) - 1)]

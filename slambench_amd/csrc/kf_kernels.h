@@ -130,6 +130,7 @@ unsigned pyramid_tiles(unsigned W, unsigned H);
 unsigned pyramid_side_rounds(unsigned tiles, unsigned icp_nb);
 bool pyramid_fusable(int n_levels, unsigned W, unsigned H);
 unsigned track_blocks_max();
+unsigned icp_tail_unit();      // workgroups of one co-residency unit of k_icp_tail (32)
 unsigned icp_blocks(unsigned w, unsigned h);
 void init_volume(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void preprocess(float *floatDepth, float *filtered, unsigned W, unsigned H, const uint16_t *in, unsigned inW, int ratio,
@@ -164,7 +165,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, hipStream_t s);   // ca != nullptr: also does icp_final's work
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, unsigned max_wgs, hipStream_t s);   // ca != nullptr: also does icp_final's work; max_wgs: workgroups the barrier may span
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
 void update_pose(M4 *pose, const float *reduction32, float icp_threshold, int *converged, hipStream_t s);

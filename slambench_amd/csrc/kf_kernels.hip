@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // first ICP_TAIL_HEAD iterations of a level in ordinary launches so that this is rare.
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
-constexpr unsigned ICP_TAIL_BLOCKS = 32;
+constexpr unsigned ICP_TAIL_BLOCKS = 32;        // one reservation unit (kf_pipeline.hip); a launch may be given several
 #ifndef KFH_TAIL_PROBE_NO_RARE
 #define KFH_TAIL_PROBE_NO_RARE 0
 #endif
@@ -2454,6 +2454,7 @@ unsigned track_blocks(unsigned w, unsigned h) {
 }
 
 unsigned track_blocks_max() { return TR_MAX_BLOCKS; }
+unsigned icp_tail_unit() { return ICP_TAIL_BLOCKS; }
 
 // Debugging aid shared by the traced kernels: <ENV>=<file> makes the 200th launch write four 64-bit words per wave
 // ({start, end} on the 100 MHz wall clock and two kernel-specific values) and dumps them (profiles/ray_trace.py).
@@ -2694,7 +2695,7 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
               const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, hipStream_t s) {
+              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, unsigned max_wgs, hipStream_t s) {
     // (the launch before `it` is an ordinary one of the same level: prev_level = level, prev_nblocks = nblocks)
     IcpIterArgs a = make_icp_args(st, iters, (it + 1) & 1 ? part1 : part0, it & 1 ? part1 : part0, result_map, it, level, level,
                                   nblocks, nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
@@ -2708,7 +2709,8 @@ void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *re
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
     static WaveTrace wt("KFH_ICP_TAIL_TRACE");
     t.trace = (ca && level == 0) ? wt.arm(2, s) : nullptr;
-    const unsigned wgs = nblocks < ICP_TAIL_BLOCKS ? nblocks : ICP_TAIL_BLOCKS;
+    const unsigned cap = max_wgs ? max_wgs : ICP_TAIL_BLOCKS;       // (the caller has reserved that many CUs for its barrier launches)
+    const unsigned wgs = nblocks < cap ? nblocks : cap;
     if (rows_ahead) k_icp_tail<true><<<wgs, ICP_THREADS, 0, s>>>(a, t);
     else k_icp_tail<false><<<wgs, ICP_THREADS, 0, s>>>(a, t);
     launched("k_icp_tail");

@@ -73,7 +73,7 @@ struct kfh_context {
     unsigned seen_failed_frames = 0;
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
-    bool barrier_slot = false;         // holds one of the device's eight k_icp_tail slots (create_common; returned by kfh_destroy)
+    int barrier_units = 0;             // units of 32 CUs (of the device's eight) reserved for this context's k_icp_tail launches (create_common; returned by kfh_destroy)
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
     struct PendingFrame {
@@ -137,7 +137,7 @@ struct kfh_context {
 // backends keep file-scope state, so kfh_synchronise_all() waits for all of them
 static std::mutex g_registry_mu;
 static std::vector<kfh_context *> g_registry;
-static std::map<int, int> g_barrier_slots;   // per device: contexts holding one of the eight co-residency slots of k_icp_tail (guarded by g_registry_mu)
+static std::map<int, int> g_barrier_slots;   // per device: units of 32 CUs (of eight) reserved for the grid barriers of k_icp_tail (guarded by g_registry_mu)
 
 static hipEvent_t prof_event(kfh_context *c, int phase) {
     std::vector<hipEvent_t> &v = c->prof_events[phase];
@@ -336,14 +336,15 @@ static void fill_side_pyramid(const kfh_context *c, const NextFrameWork &nw, Sid
 }
 
 // How many of a level's last iterations share one launch (k_icp_tail): everything after the first `icp_tail_head`
-// (KFH_ICP_TAIL_HEAD, one value or a list by level; 0 = every iteration gets its own launch), if that is at least two.  Default: 4 on
-// level 0, 3 on the coarser levels.  A launch costs >= 4.4 us however little it does (profiles/r04_launch_cost.txt) and the loop
-// stops a level after 3 iterations in ~90 % of the frames: on level 1 (5 iterations) the tail then replaces the launch that finds
-// the level converged AND the one after it (cfg2 ICP loop 110.7 -> 108.5 us); on level 0 a third of a microsecond either way
-// (an iteration that does run inside the tail costs ~37 us there against ~14 on level 1), so its fourth iteration keeps its launch.
+// (KFH_ICP_TAIL_HEAD, one value or a list by level; 0 = every iteration gets its own launch), if that is at least two.  Default: 3,
+// and 4 on level 0 for a context whose shared launches are 32 workgroups wide.  A launch costs >= 4.4 us however little it does
+// (profiles/r04_launch_cost.txt) and the loop stops a level after 3 iterations in ~90 % of the frames: on level 1 (5 iterations) the
+// tail then replaces the launch that finds the level converged AND the one after it (cfg2 ICP loop 110.7 -> 108.5 us).  On level 0
+// an iteration that does run inside a 32-workgroup tail costs ~37 us (~14 on level 1), which made its fourth iteration a wash; with
+// 64 workgroups (create_common: the first context of a device) it joins the tail: 102.4 -> 100.3 us (profiles/r04_wide_tail.txt).
 static int tail_length(const kfh_context *c, int level) {
     const int n = c->iterations[level];
-    const int head = c->icp_tail_head.empty() ? (level == 0 ? 4 : 3) : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
+    const int head = c->icp_tail_head.empty() ? ((level == 0 && c->barrier_units < 2) ? 4 : 3) : c->icp_tail_head[std::min((size_t)level, c->icp_tail_head.size() - 1)];
     if (head <= 0 || n - head < 2) return 0;
     return n - head;
 }
@@ -479,7 +480,8 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             closed = level == 0 && fold_env;      // the loop's last launch: it applies the final update and end_ops too
             launch::icp_tail(c->d_state, c->d_icp, part[0], part[1], c->d_result, it, n_tail, level, nb, c->d_inV[level],
                              c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold, dist_threshold,
-                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, /* rows_ahead: the iteration before the launch usually ran */ n_plain < 4, c->stream);
+                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, /* rows_ahead: the iteration before the launch usually ran */ n_plain < 4,
+                             (unsigned)c->barrier_units * launch::icp_tail_unit(), c->stream);
             it += n_tail;
         }
     }
@@ -726,15 +728,24 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     ok &= HIP_TRY(hipMalloc(&c->d_partials, (size_t)2 * launch::track_blocks_max() * 32 * sizeof(float)));
     c->icp_tail_head = parse_int_list(getenv("KFH_ICP_TAIL_HEAD"));
     {
-        // k_icp_tail synchronises its <= 32 workgroups (one CU each) with a grid barrier: they must be resident together.  Eight
-        // such launches fit the 256 CUs at once whatever else runs, so up to eight contexts per device may use it; a ninth
-        // gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could time out.
-        // The slot is RESERVED here, under the registry lock (the context itself joins the registry only when it is complete): two
-        // threads creating contexts at once cannot both take the eighth.  kfh_destroy gives it back, also for a creation that fails.
+        // k_icp_tail synchronises its workgroups (one CU each) with a grid barrier: they must be resident together.  The 256 CUs
+        // are handed out in eight units of 32: whatever else runs, launches whose widths add up to no more than 256 can all become
+        // resident.  The FIRST context of a device in this process takes two units - 64 workgroups run a late iteration of level 0
+        // in ~half the time 32 need, which lets level 0's fourth iteration join the shared launch (tail_length; cfg2 ICP loop
+        // 102.4 -> 100.3 us, profiles/r04_wide_tail.txt; 128 workgroups: 100.0) -, every further one a single unit, and a context that
+        // finds none left gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could
+        // time out.  Reserved here, under the registry lock (the context itself joins the registry only when it is complete): two
+        // threads creating contexts at once cannot overbook.  kfh_destroy gives the units back, also for a creation that fails.
+        // (KFH_ICP_TAIL_BLOCKS = 32 ... 256 asks for another width for every context, as long as units are left.)
+        static const int width_env = [] { const char *e = getenv("KFH_ICP_TAIL_BLOCKS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 256) ? v : 0; }();
+        const int unit = (int)launch::icp_tail_unit();
         std::lock_guard<std::mutex> lk(g_registry_mu);
         int &taken = g_barrier_slots[c->device];
-        if (taken >= 8) c->icp_tail_head.assign(1, 0);
-        else { ++taken; c->barrier_slot = true; }
+        int want = width_env ? (width_env + unit - 1) / unit : (taken == 0 ? 2 : 1);
+        if (taken + want > 8) want = taken + 1 <= 8 ? 1 : 0;
+        if (want == 0) c->icp_tail_head.assign(1, 0);
+        taken += want;
+        c->barrier_units = want;
     }
     c->icp_total = 0;
     for (int i = 0; i < n_levels; ++i) c->icp_total += pyramid[i] > 0 ? pyramid[i] : 0;
@@ -823,7 +834,7 @@ void kfh_destroy(kfh_context *c) {
         std::lock_guard<std::mutex> lk(g_registry_mu);
         for (size_t i = 0; i < g_registry.size(); ++i)
             if (g_registry[i] == c) { g_registry.erase(g_registry.begin() + i); break; }
-        if (c->barrier_slot) { --g_barrier_slots[c->device]; c->barrier_slot = false; }
+        if (c->barrier_units) { g_barrier_slots[c->device] -= c->barrier_units; c->barrier_units = 0; }
     }
     hipSetDevice(c->device);
     c->pend.valid = false;   // a frame still deferred is dropped with the context

@@ -261,7 +261,8 @@ def test_bench_timed_run_reports_a_failing_rank(capsys):
     assert err is None and leg.steps == [0, 1, 2, 3, 4] and leg.syncs == 2 and elapsed >= 0
     elapsed, leg, err = bench.timed_run(S, lambda: Leg(fail_at=3), multi, 2, 3, 1)
     assert isinstance(err, RuntimeError) and leg.steps == [0, 1, 2]
-    assert bench.icp_launches((10, 5, 4)) == 13 and bench.icp_launches((10, 5, 4, 4)) == 17
+    assert bench.icp_launches((10, 5, 4)) == 12 and bench.icp_launches((10, 5, 4, 4)) == 16
+    assert bench.icp_launches((10, 5, 4), heads=(4, 3)) == 13 and bench.icp_launches((10, 5, 4, 4), heads=(4, 3)) == 17
     assert bench.icp_launches((10, 5, 4), heads=(4,)) == 14 and bench.icp_launches((10, 5, 4, 4), heads=(4,)) == 18
 
 
