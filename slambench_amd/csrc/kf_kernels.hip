@@ -1271,8 +1271,8 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // ---- tail launch --------------------------------------------------------------------------------------------------
 // The late iterations of a level are queued for the worst case but almost never run (640x480 living room: level 0 stops
 // after 3 of its 10 iterations in 91 % of the frames, after 4 in 7 %), and an empty launch still costs ~2 us of queue
-// time.  k_icp_tail runs the last `n_its` iterations of a level in ONE launch: a few workgroups (at most ICP_TAIL_BLOCKS,
-// few enough to be resident together whatever else the device runs) loop over the iterations, each emulating the
+// time.  k_icp_tail runs the last `n_its` iterations of a level in ONE launch: a few workgroups (ICP_TAIL_BLOCKS times the
+// units the context has reserved: resident together whatever else the device runs) loop over the iterations, each emulating the
 // a.nblocks ICP blocks of an ordinary launch in turn - same pixels per block, same partial rows, same sums, hence the
 // same bits - with a grid barrier between iterations (release/acquire on a counter in DevState; the partial sums and the
 // state record are re-read with agent-scope loads).  All workgroups take the same decisions from the same data, so they
