@@ -71,3 +71,39 @@ def test_icp_level_with_a_partial_remainder(hip, kfmod, orc, W, H):
     assert f_run.get_tracked() and np.abs(f_run.get_pose() - o.get_pose()).max() <= 1e-4
     for x in (o, g1, o1, f_run, q):
         x.close()
+
+
+def test_nine_contexts_share_the_co_residency_units(hip, kfmod):
+    """k_icp_tail's grid barrier needs its workgroups resident together, so a process hands out the device's 256 CUs in eight units of
+    32 (kf_pipeline.hip create_common): the first context of a device takes two (its shared launches are 64 workgroups wide and carry
+    level 0's fourth iteration), the next six one each, and the eighth and ninth find none left and get a launch per iteration.  The
+    schedule is never an input of the computation: with every queued iteration forced to run (threshold 0: the late ones inside 64- and
+    32-workgroup launches, or in launches of their own) all nine contexts, taking turns on the device, must produce the same bits - and
+    the units must come back when the contexts go."""
+    n = 8
+    s = util.small_stream(n)
+    k = list(s.k)
+    res = (48, 48, 48)
+    mk = lambda: kfmod.Kfusion((s.width, s.height), res, util.VOL_DIM, s.init_pos, (10, 5, 4))
+    ctxs = [mk() for _ in range(9)]
+    for f in range(n):
+        for c in ctxs:
+            c.compute_frame(s.depth_mm[f], (s.width, s.height), k, 1, 1, 0.0, util.MU, f)
+    for c in ctxs:
+        c.synchronise()
+    assert ctxs[0].icp_level_iterations() == [10 * n, 5 * n, 4 * n]
+    ref = {name: ctxs[0].buffer(name).copy() for name in ("pose", "volume", "vertex", "normal", "trackResult")}
+    for i, c in enumerate(ctxs[1:], 1):
+        assert c.icp_level_iterations() == ctxs[0].icp_level_iterations(), i
+        assert c.barrier_timeouts() == 0, i
+        for name, want in ref.items():
+            assert np.array_equal(c.buffer(name).view(np.uint8), want.view(np.uint8)), (i, name)
+    for c in ctxs:
+        c.close()
+    again = mk()                        # the units are back: this one is a first context again and runs like one
+    for f in range(n):
+        again.compute_frame(s.depth_mm[f], (s.width, s.height), k, 1, 1, 0.0, util.MU, f)
+    again.synchronise()
+    for name, want in ref.items():
+        assert np.array_equal(again.buffer(name).view(np.uint8), want.view(np.uint8)), name
+    again.close()
