@@ -58,7 +58,8 @@ V_FRAMES = 2            # frames after the cpu_baseline prefix on which the orac
 
 
 def icp_launches(pyramid, heads=(3, 3)):
-    """launches of a frame's ICP loop: per level the first `head` iterations one each (3 for the first context of a device, whose
+    """launches of a frame's ICP loop for the FIRST context of a device (what a context really queues is kfh_icp_launches_per_frame,
+    which the roofline entry uses; this twin of it is what the CPU tests check the schedule against): per level the first `head` iterations one each (3 for the first context of a device, whose
     shared launch is 64 workgroups wide; 4 on level 0 for further contexts), the rest (if >= 2) share one (kf_pipeline.hip
     tail_length); the level-0 tail also closes the loop, otherwise k_icp_final does"""
     n, closed = 0, False
@@ -486,7 +487,7 @@ def traffic_of(config, measure):
     return traffic, source
 
 
-def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct, measure=False):
+def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct, measure=False, icp_launch_count=None):
     """roofline entries of k_integrate, k_raycast and the ICP loop: algorithmic bytes / HIP-event time of this run"""
     W, H, vres, pyramid, irate, zrate = cfg
     traffic, source = traffic_of(config_name, measure)
@@ -528,7 +529,7 @@ def rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_le
         alg = alg_icp + alg_pre
         avg_s = ms / n * 1e-3
         gbs = alg / avg_s / 1e9
-        roof["icp"] = {"kernel": "k_icp_iter* + k_icp_tail (one frame's ICP loop: %d queued iterations in %d launches)" % (sum(pyramid), icp_launches(pyramid)), "bound": "hbm",
+        roof["icp"] = {"kernel": "k_icp_iter* + k_icp_tail (one frame's ICP loop: %d queued iterations in %d launches)" % (sum(pyramid), icp_launch_count or icp_launches(pyramid)), "bound": "hbm",
                        "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
                        "traffic": traffic.get("icp"), "traffic_source": source if traffic.get("icp") else None, "avg_us": round(avg_s * 1e6, 2), "launches": n,
                        "sampled_every_n_frames": prof_every, "algorithmic_bytes_per_launch": round(alg),
@@ -603,7 +604,7 @@ def measure(S, args, multi, config_name, steps, warmup, full):
 
     elapsed, leg, err = timed_run(S, lambda: mk(False, spg - 1, host_input=full and args.host_input), multi, warmup, steps, prof_every)
     failed, errs = 0, [0.0]
-    prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = None
+    prof = updated = icp_iters = icp_by_level = fallbacks = tracked = integrated = icp_launch_count = None
     try:
         if err is not None:
             raise err
@@ -613,6 +614,7 @@ def measure(S, args, multi, config_name, steps, warmup, full):
             updated = kf.integrate_updated()
             icp_iters = kf.icp_iterations()
             icp_by_level = kf.icp_level_iterations()
+            icp_launch_count = kf.icp_launches_per_frame()      # as THIS context queues them (its shared-launch width decides)
             if kf.barrier_timeouts():
                 raise RuntimeError("k_icp_tail: %d workgroups timed out at the grid barrier - the run is invalid" % kf.barrier_timeouts())
             fallbacks = kf.solve_fallbacks()
@@ -653,7 +655,7 @@ def measure(S, args, multi, config_name, steps, warmup, full):
     if full and not args.no_host_buffers and S.world == 1:
         host = host_buffers_leg(wl, cfg, n_frames)
     roof = rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct,
-                     measure=S.world == 1 and not args.no_measure_traffic)
+                     measure=S.world == 1 and not args.no_measure_traffic, icp_launch_count=icp_launch_count)
     res = {
         "workload": workload_string(config_name, cfg, wl),
         "value": round(total_frames / t_max, 2), "ms_per_step": round(t_max / (steps * spg) * 1e3, 4), "steps": steps, "warmup": warmup,

@@ -125,6 +125,9 @@ void kfh_get_computation_resolution(kfh_context *ctx, uint32_t out2[2]);
 int kfh_read_frame_log(kfh_context *ctx, uint32_t n, float *poses16_out, int32_t *tracked_out, int32_t *integrated_out);
 /* ICP iterations actually executed since the context was created (device counter). */
 uint64_t kfh_icp_iterations(kfh_context *ctx);
+/* launches a tracked frame's ICP loop takes in this context (the late iterations of a level share one; how many do depends on the
+ * co-residency the context reserved at creation - bench.py's roofline entry divides by it) */
+uint32_t kfh_icp_launches_per_frame(kfh_context *ctx);
 /* The same by pyramid level (index 0 = full resolution); out has KFH_MAX_LEVELS entries. */
 void kfh_icp_level_iterations(kfh_context *ctx, uint64_t out[KFH_MAX_LEVELS]);
 /* Voxels updated by all integrate launches so far (U of SURVEY.md §8d; device counter). */

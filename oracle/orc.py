@@ -351,6 +351,10 @@ class OracleKfusion:
     def _k(k):
         return (C.c_float * 4)(*k)
 
+    def reset(self):
+        """Kfusion::reset (cpp:135-137): the volume back to its initial state, nothing else"""
+        self.L.orc_kfusion_reset(self.h)
+
     def preprocessing(self, depth_mm):
         depth_mm = np.ascontiguousarray(depth_mm, np.uint16)
         return self.L.orc_kfusion_preprocessing(self.h, _p(depth_mm, C.c_ushort), depth_mm.shape[1], depth_mm.shape[0]) == 1

@@ -52,6 +52,7 @@ SIGNATURES = {
     "kfh_get_computation_resolution": (None, [vp, u32p]),
     "kfh_read_frame_log": (i32, [vp, u, fp, i32p, i32p]),
     "kfh_icp_iterations": (u64, [vp]),
+    "kfh_icp_launches_per_frame": (u, [vp]),
     "kfh_icp_level_iterations": (None, [vp, C.POINTER(C.c_uint64)]),
     "kfh_integrate_updated": (u64, [vp]),
     "kfh_solve_fallbacks": (u64, [vp]),

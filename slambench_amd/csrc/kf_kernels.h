@@ -159,12 +159,12 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s);
+              float icp_threshold, float dist_threshold, float dist2_max, float normal_threshold, const SideWork *side, hipStream_t s);
 // the last n_its iterations of a level (it .. it + n_its - 1, all after an ordinary launch of that level) in one launch;
 // if it is the last launch of the frame's loop it can apply the final update and the control operations too
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
-              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
+              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float dist2_max, float normal_threshold,
               FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, unsigned max_wgs, hipStream_t s);   // ca != nullptr: also does icp_final's work; max_wgs: workgroups the barrier may span
 void icp_final(DevState *st, FrameLogEntry *log, const IcpState *iters, const float *partials_prev, int n_iters,
                int prev_level, unsigned prev_nblocks, float icp_threshold, int ops, const ControlArgs &a, hipStream_t s);
@@ -183,7 +183,7 @@ size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz);
 void prepare_volume_division(f3 dim, unsigned sx, unsigned sy, unsigned sz, hipStream_t s);
 void prepare_bilateral_division(float e_d, hipStream_t s);
 // verifies once per device and threshold (~1 ms, synchronises the stream) that length > t may be decided on the squared length (sqrt_gt_bound)
-void prepare_sqrt_bound(float t, hipStream_t s);
+float prepare_sqrt_bound(float t, hipStream_t s);
 // one-off self-check of the ICP block reduction's inline-assembly lane exchanges against the same tree written with plain shuffles:
 // 1 verified, 0 mismatch (remembered per device), -1 the check itself could not run (a HIP error; not remembered)
 int reduction_verified(hipStream_t s);

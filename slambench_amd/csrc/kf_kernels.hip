@@ -328,10 +328,16 @@ struct PyrGeom {
 // rounds of tiles (1280x960) the stores of one round drain while the next computes, and going through costs +2.3 us a launch
 // (profiles/r04_ab_pyr_wt.txt).
 typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_through(bool through, float4 *p, float x, float y, float z, float w) {
-    // (as an instruction, not a volatile access: the compiler would wait for each of those before issuing the next)
-    if (through) { const v4f_t v{x, y, z, w}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory"); }    // (s_nop: the data registers may be rewritten next)
-    else *p = make_float4(x, y, z, w);
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_through(bool through, float4 *base, size_t idx, float x, float y, float z, float w) {
+    // (a raw buffer store with the sc0 sc1 bits - aux 0x11 on gfx950 - not a volatile access, which the compiler would wait for
+    // before issuing the next, and not inline assembly, which its hazard recogniser and its count of outstanding memory
+    // operations cannot see: the map's base is wave-uniform, the pixel's byte offset the per-lane part; maps are < 4 GiB)
+    if (through) {
+        const v4f_t v{x, y, z, w};
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0xFFFFFFFFu, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), rsrc, (int)((unsigned)idx * 16u), 0, 0x11);
+    } else base[idx] = make_float4(x, y, z, w);
 }
 
 template <int NLEV, int L, int NTHR>
@@ -397,20 +403,14 @@ __device__ __forceinline__ void pyramid_level(const PyramidArgs &a, float *lds, 
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
         if (on[r] && bad[r] && stale) old[r] = stale[where[r]];
-    // store_through's instruction is invisible to the compiler's count of outstanding memory operations, and a store may retire
-    // before an older load: a `vmcnt(n)` computed for a load would be met early by it.  So nothing of the compiler's is in flight
-    // when the first of them is issued, and none of them when the compiler's next load is.
-    if (a.through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (!on[r]) continue;
-        store_through(a.through, a.vertex[L] + where[r], vc[r].x, vc[r].y, vc[r].z, 0.f);
-        float4 *out = a.normal[L] + where[r];
-        if (!bad[r]) store_through(a.through, out, vn[r].x, vn[r].y, vn[r].z, 0.f);
-        else if (stale) store_through(a.through, out, kInvalid, old[r].y, old[r].z, old[r].w);      // SURVEY N3, as store_normal
-        else reinterpret_cast<float *>(out)[0] = kInvalid;
+        store_through(a.through, a.vertex[L], where[r], vc[r].x, vc[r].y, vc[r].z, 0.f);
+        if (!bad[r]) store_through(a.through, a.normal[L], where[r], vn[r].x, vn[r].y, vn[r].z, 0.f);
+        else if (stale) store_through(a.through, a.normal[L], where[r], kInvalid, old[r].y, old[r].z, old[r].w);      // SURVEY N3, as store_normal
+        else reinterpret_cast<float *>(a.normal[L] + where[r])[0] = kInvalid;
     }
-    if (a.through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // One 32x32 level-0 tile by the NTHR threads of a block.  UPPER_ONLY: the maps of level 0 are somebody else's (a
@@ -1282,9 +1282,6 @@ __device__ __forceinline__ void close_icp_loop(IcpShared &sh, DevState *st, Fram
 // A workgroup that waits longer than ~2 s at the barrier (which needs another process to hog the device) counts a
 // time-out in DevState::barrier_timeouts and carries on, so the grid always drains; kfh reports the frame as failed.
 constexpr unsigned ICP_TAIL_BLOCKS = 32;        // one reservation unit (kf_pipeline.hip); a launch may be given several
-#ifndef KFH_TAIL_PROBE_NO_RARE
-#define KFH_TAIL_PROBE_NO_RARE 0
-#endif
 
 struct IcpTailArgs {
     float *part[2]; int n_its; unsigned *barrier; unsigned *timeouts;
@@ -1368,11 +1365,7 @@ __global__ __launch_bounds__(ICP_THREADS, ICP_WAVES_PER_SIMD) void k_icp_tail(Ic
         }
         ICP_STAMP(2);
     } else {
-#if KFH_TAIL_PROBE_NO_RARE      // timing probe only (results are wrong whenever a late iteration is due): what the scratch the loop declares costs the usual path
-        close = closes && writer;
-#else
         close = icp_tail_iterations(sh, a, t);
-#endif
     }
     // block 0 of the launch that ends the frame's ICP loop: what k_icp_final does after its own icp_advance
     if (close) close_icp_loop(sh, a.st, t.log, t.final_ops, t.ca);
@@ -1541,14 +1534,16 @@ template <bool KZ> __device__ __forceinline__ void march_step(ColumnState &S, v2
 }
 template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) { return KZ ? S.b.x : S.cz; }
 
-#ifndef KFH_INT_PROBE_NO_REPLAY
-#define KFH_INT_PROBE_NO_REPLAY 0
+// Stage probes for the instruction census (profiles/r05_integrate_census.txt): ONLY in a build with -DKFH_INT_PROBES=1 (through
+// KFH_EXTRA_HIPCC_FLAGS) does the kernel look at `dbg` - results are wrong with a probe on; the shipped library has no such path
+// (tests/test_capi_symbols.py greps the default build for the switch's name).
+#ifndef KFH_INT_PROBES
+#define KFH_INT_PROBES 0
 #endif
-#ifndef KFH_INT_SPECULATE
-#define KFH_INT_SPECULATE 0
-#endif
-#ifndef KFH_INT_IDLE_EXIT
-#define KFH_INT_IDLE_EXIT 1
+#if KFH_INT_PROBES
+#define KFH_INT_PROBE(bit) ((dbg & (bit)) != 0)
+#else
+#define KFH_INT_PROBE(bit) false
 #endif
 #ifndef KFH_INTEGRATE_WAVES_PER_SIMD
 #define KFH_INTEGRATE_WAVES_PER_SIMD 5      // occupancy floor handed to the register allocator (5 = at most 96 VGPRs)
@@ -1605,7 +1600,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         // does: the chunk updates nothing and the thread leaves without replaying its z0 additions.  Four of five chunks
         // lie outside the frustum; what remains pays the replay, which is what lets the chunks be short (see integrate_grid).
         bool chunk_out = false;
-        if (!(dbg & 8)) {
+        if (!KFH_INT_PROBE(8)) {
             const float zf = (float)z0, zl = (float)(z1 - 1);
             const float n_err = (float)(sz + 4) * 5.9604645e-8f;
             const float E = n_err * P.cam_bound, Ez = n_err * P.far_bound;
@@ -1625,17 +1620,8 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             chunk_out = chunk_out || behind;
         }
-#if KFH_INT_PROBE_NO_REPLAY      // timing probe (a build flag: the extra path costs the kept kernel a register spill): the state at z0 from
-        if (!chunk_out) {        // one multiply-add per sum - right to a few ulps, not to the bit (profiles/r02_sweeps.md)
-            const float zf = (float)z0;
-            S.a.x = __builtin_fmaf(zf, da.x, S.a.x); S.a.y = __builtin_fmaf(zf, da.y, S.a.y);
-            S.b.x = __builtin_fmaf(zf, db.x, S.b.x); S.b.y = __builtin_fmaf(zf, db.y, S.b.y);
-            S.cy = __builtin_fmaf(zf, dc.x, S.cy); S.cz = __builtin_fmaf(zf, dc.y, S.cz);
-        }
-#else
         if (!chunk_out)
         for (unsigned z = 0; z < z0; ++z) { march_step<KZ>(S, da, db, dc); }
-#endif
         const size_t plane = (size_t)sx * sy;
         short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -1674,7 +1660,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 if (batch_ok && cz_f > 0.05f && cz_l > 0.05f)
                     outside = (outside_bits(first.b.y, first.cy, cz_f, -0.75f, wlim_b, hlim_b) &
                                outside_bits(last.b.y, last.cy, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
-                if (behind || outside || (dbg & 1)) continue;   // dbg: timing probes only (KFH_INTEGRATE_DBG)
+                if (behind || outside || KFH_INT_PROBE(1)) continue;
             }
             // detailed pass over the batch, replaying the additions from its first voxel
             ColumnState T = first;
@@ -1709,20 +1695,11 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 }
             }
             ++work;
-            if (!live || (dbg & 2)) continue;
+            if (!live || KFH_INT_PROBE(2)) continue;
             float d[IB];
-#if KFH_INT_SPECULATE
-            // the voxels are requested WITH the depths that decide whether they are needed (one memory round trip per batch
-            // instead of two in a row; the voxels behind the surface are fetched for nothing)
-            short2 c[IB];
-#pragma unroll
-            for (int i = 0; i < IB; ++i)
-                if (live & (1u << i)) { d[i] = depth[pix[i]]; c[i] = cell[(size_t)i * plane]; }
-#else
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (live & (1u << i)) d[i] = depth[pix[i]];
-#endif
             // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
             unsigned need = 0;
             float t_[IB];
@@ -1737,14 +1714,12 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 t_[i] = t;
                 need |= 1u << i;
             }
-            if (!need || (dbg & 4)) continue;
+            if (!need || KFH_INT_PROBE(4)) continue;
             work += 4;
-#if !KFH_INT_SPECULATE
             short2 c[IB];
 #pragma unroll
             for (int i = 0; i < IB; ++i)
                 if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
-#endif
             // the world position of a band voxel is replayed from the batch's first state (3 packed adds per voxel) instead
             // of being kept in 24 registers across the two memory round trips above
             ColumnState R = first;
@@ -1771,11 +1746,9 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
         }
     }
-#if KFH_INT_IDLE_EXIT
     // two of three waves examined nothing (their chunks lie outside the frustum): nothing to add to the cost table or the
     // counter, so they leave here instead of running two six-step wave reductions over zeros
     if (!trace && __builtin_amdgcn_ballot_w64((work | updated) != 0u) == 0ull) return;
-#endif
     if (cost || trace) {   // cost of the block = the busiest lane of its waves: batches examined + 4 x batches updated
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) work = umax_(work, (unsigned)__shfl_xor((int)work, off, 64));
@@ -2273,9 +2246,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
     const bool padding = tslot >= sg.tiles_x * sg.tiles_y;      // (the launch is padded to a multiple of 8 * PARTS slots)
     const unsigned tile = (sg.order && !padding) ? sg.order[tslot] : tslot;
     asm volatile("" : : "s"(R.view.m[0][0]), "s"(R.view.m[2][0]), "s"(tile));
-    if (!R.enabled) return;
+    // (the riding preamble first: the host books it as done whenever this launch was enqueued, whatever the raycast gate says -
+    // k_icp_tail's barrier counters are reset there)
     if (sg.next_state && slot == gridDim.x * gridDim.y - 1 && threadIdx.x == 0)
         track_begin(sg.next_state, (sg.next_frame % sg.next_tracking_rate) == 0, sg.next_k);
+    if (!R.enabled) return;
     if (padding) return;
     unsigned x, y;
     {
@@ -2580,18 +2555,16 @@ void control(DevState *st, FrameLogEntry *log, int ops, const ControlArgs &a, hi
     k_control<<<1, 64, 0, s>>>(st, log, ops, a); launched("k_control");
 }
 
-static bool sqrt_bound_verified(float t);
-
 static IcpIterArgs make_icp_args(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map,
                                  int it, int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV,
                                  const float4 *inN, unsigned inW, unsigned inH, const float4 *refV, const float4 *refN,
-                                 unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold) {
+                                 unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float dist2_max, float normal_threshold) {
     IcpIterArgs a;
     a.st = st; a.iters = iters; a.partials_prev = partials_prev; a.partials_out = partials_out; a.result_map = result_map;
     a.it = it; a.level = level; a.prev_level = prev_level; a.prev_nblocks = prev_nblocks; a.nblocks = nblocks;
     a.inV = inV; a.inN = inN; a.inW = inW; a.inH = inH; a.refV = refV; a.refN = refN; a.refW = refW; a.refH = refH;
     a.icp_threshold = icp_threshold; a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
-    a.dist2_max = sqrt_bound_verified(dist_threshold) ? sqrt_gt_bound(dist_threshold) : -1.f;
+    a.dist2_max = dist2_max;      // (the context's verdict of prepare_sqrt_bound at kfh_create: no look-up on the frame path)
     // py = (unsigned)((p + 0.5f) * RN(1 / inW)) is p / inW while p + 0.5 and the two roundings leave more than the 0.5 / inW
     // between (p + 0.5) / inW and the next integer: certainly for p < 2^22
     a.inv_inW = ((unsigned long long)inW * inH <= (1ull << 22)) ? 1.0f / (float)inW : 0.f;
@@ -2620,10 +2593,10 @@ bool pyramid_fusable(int n_levels, unsigned W, unsigned H) {
 void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *partials_out, int *result_map, int it,
               int level, int prev_level, unsigned prev_nblocks, unsigned nblocks, const float4 *inV, const float4 *inN,
               unsigned inW, unsigned inH, const float4 *refV, const float4 *refN, unsigned refW, unsigned refH,
-              float icp_threshold, float dist_threshold, float normal_threshold, const SideWork *side, hipStream_t s) {
+              float icp_threshold, float dist_threshold, float dist2_max, float normal_threshold, const SideWork *side, hipStream_t s) {
     IcpIterArgs a = make_icp_args(st, iters, partials_prev, partials_out, result_map, it, level, prev_level, prev_nblocks,
                                         nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
-                                        normal_threshold);
+                                        dist2_max, normal_threshold);
     if (side && side->kind == SideWork::BILATERAL && side->count) {
         SideBilateral sb;
         sb.floatDepth = side->floatDepth; sb.out = side->filtered; sb.in = side->in; sb.W = side->W; sb.H = side->H;
@@ -2694,16 +2667,20 @@ void icp_iter(DevState *st, IcpState *iters, const float *partials_prev, float *
 
 void icp_tail(DevState *st, IcpState *iters, float *part0, float *part1, int *result_map, int it, int n_its, int level,
               unsigned nblocks, const float4 *inV, const float4 *inN, unsigned inW, unsigned inH, const float4 *refV,
-              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float normal_threshold,
-              FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, unsigned max_wgs, hipStream_t s) {
+              const float4 *refN, unsigned refW, unsigned refH, float icp_threshold, float dist_threshold, float dist2_max,
+              float normal_threshold, FrameLogEntry *log, int final_ops, const ControlArgs *ca, bool rows_ahead, unsigned max_wgs, hipStream_t s) {
     // (the launch before `it` is an ordinary one of the same level: prev_level = level, prev_nblocks = nblocks)
     IcpIterArgs a = make_icp_args(st, iters, (it + 1) & 1 ? part1 : part0, it & 1 ? part1 : part0, result_map, it, level, level,
                                   nblocks, nblocks, inV, inN, inW, inH, refV, refN, refW, refH, icp_threshold, dist_threshold,
-                                  normal_threshold);
+                                  dist2_max, normal_threshold);
     IcpTailArgs t;
     t.part[0] = part0; t.part[1] = part1; t.n_its = n_its;
     t.barrier = &st->tail_barrier[level]; t.timeouts = &st->barrier_timeouts;
-    static const long long ticks_env = [] { const char *e = getenv("KFH_ICP_TAIL_TIMEOUT_TICKS"); return e ? atoll(e) : -1LL; }();
+    // (a forced time-out fails frames: the switch is a test hook, honoured only with KFH_ENABLE_TEST_HOOKS=1 beside it)
+    static const long long ticks_env = [] {
+        const char *hooks = getenv("KFH_ENABLE_TEST_HOOKS"), *e = getenv("KFH_ICP_TAIL_TIMEOUT_TICKS");
+        return (hooks && hooks[0] == '1' && e) ? atoll(e) : -1LL;
+    }();
     t.timeout_ticks = ticks_env >= 0 ? (unsigned long long)ticks_env : 200000000ull;
     t.final_ops = ca ? final_ops : -1; t.log = log;
     if (ca) t.ca = *ca; else t.ca = ControlArgs{};
@@ -2800,21 +2777,15 @@ static bool verified_divisor(float d, hipStream_t s) {
 struct SqrtBoundEntry { int dev; float t; bool ok; };
 static std::vector<SqrtBoundEntry> g_sqrt_bounds;
 static std::mutex g_sqrt_bounds_mu;
-static bool sqrt_bound_verified(float t) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_sqrt_bounds_mu);
-    for (const SqrtBoundEntry &e : g_sqrt_bounds) if (e.dev == dev && e.t == t) return e.ok;
-    return false;
-}
-void prepare_sqrt_bound(float t, hipStream_t s) {
+// returns the bound to compare squared lengths with (>= 0) or -1 = take the square root; the context keeps it
+float prepare_sqrt_bound(float t, hipStream_t s) {
     static const bool allow = [] { const char *e = getenv("KFH_EXACT_SQRT"); return !(e && e[0] == '0'); }();
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_sqrt_bounds_mu);
-    for (const SqrtBoundEntry &e : g_sqrt_bounds) if (e.dev == dev && e.t == t) return;
-    bool ok = false, ran = true;
     const float bound = sqrt_gt_bound(t);
+    for (const SqrtBoundEntry &e : g_sqrt_bounds) if (e.dev == dev && e.t == t) return e.ok ? bound : -1.f;
+    bool ok = false, ran = true;
     if (allow && bound >= 0.f) {
         unsigned long long *dm = nullptr;
         ran = hipMalloc(&dm, sizeof *dm) == hipSuccess;
@@ -2828,6 +2799,7 @@ void prepare_sqrt_bound(float t, hipStream_t s) {
         }
     }
     if (ran) g_sqrt_bounds.push_back(SqrtBoundEntry{dev, t, ok});      // (a check that could not run is not remembered)
+    return ok ? bound : -1.f;
 }
 
 // all three axes verified and every numerator pos * size below 2^24
@@ -2929,12 +2901,16 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
                const IntegrateParams *p, float mu, float maxweight, unsigned long long *updated_total, unsigned char *skip_flags,
                unsigned *block_order, unsigned *block_cost, bool k_trivial, hipStream_t s) {
     static const long batch_env = env_long("KFH_INTEGRATE_BATCH", 1, 16, 8);
-    // timing probes (results are wrong with them): 1 every batch rejected, 2 stop after the projection pass, 4 stop after the depth
-    // classification, 8 no whole-chunk reject; KFH_INTEGRATE_DBG_FROM = first launch they apply to (the state before is real)
-    static const int dbg_env = (int)env_long("KFH_INTEGRATE_DBG", 0, 15, 0);
-    static const long dbg_from = env_long("KFH_INTEGRATE_DBG_FROM", 0, 1000000, 0);
+#if KFH_INT_PROBES
+    // census build only (-DKFH_INT_PROBES=1; results are wrong with a probe on): 1 every batch rejected, 2 stop after the projection
+    // pass, 4 stop after the depth classification, 8 no whole-chunk reject; KFH_INT_PROBE_FROM = first launch they apply to
+    static const int dbg_env = (int)env_long("KFH_INT_PROBE_STAGE", 0, 15, 0);
+    static const long dbg_from = env_long("KFH_INT_PROBE_FROM", 0, 1000000, 0);
     static std::atomic<long> n_launch{0};
     const int dbg = (dbg_env && n_launch.fetch_add(1) >= dbg_from) ? dbg_env : 0;
+#else
+    const int dbg = 0;
+#endif
     unsigned zchunk;
     const dim3 grid = integrate_grid(sx, sy, sz, &zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);

@@ -73,6 +73,7 @@ struct kfh_context {
     unsigned seen_failed_frames = 0;
     bool queued_api = false;           // the caller's last frame came through kfh_compute_frame (renders then stay asynchronous)
     int error = KFH_OK;                // sticky: KFH_ERR_BARRIER / KFH_ERR_HIP once a frame failed on the device or a launch was rejected
+    float dist2_max = -1.f;            // the ICP association's squared-length bound verified on this device at creation (launch::prepare_sqrt_bound), -1 = square root
     int barrier_units = 0;             // units of 32 CUs (of the device's eight) reserved for this context's k_icp_tail launches (create_common; returned by kfh_destroy)
     std::vector<int> icp_tail_head;    // per level (last value repeats): iterations with a launch of their own; the rest share one (tail_length)
     bool pipelined = false;            // kfh_compute_frame defers tracking/integration/raycast of a frame to the next call
@@ -472,7 +473,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             }
             launch::icp_iter(c->d_state, c->d_icp, part[(it + 1) & 1], part[it & 1], c->d_result, it, level, prev_level, prev_nb,
                              nb, c->d_inV[level], c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold,
-                             dist_threshold, normal_threshold, sp, c->stream);
+                             dist_threshold, c->dist2_max, normal_threshold, sp, c->stream);
             prev_level = level; prev_nb = nb; ++it;
         }
         if (n_tail > 0) {   // the rarely needed late iterations of the level, one launch (k_icp_tail)
@@ -480,7 +481,7 @@ static bool enqueue_tracking(kfh_context *c, const float k[4], float icp_thresho
             closed = level == 0 && fold_env;      // the loop's last launch: it applies the final update and end_ops too
             launch::icp_tail(c->d_state, c->d_icp, part[0], part[1], c->d_result, it, n_tail, level, nb, c->d_inV[level],
                              c->d_inN[level], w, h, c->d_vertex, c->d_normal, c->W, c->H, icp_threshold, dist_threshold,
-                             normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, /* rows_ahead: the iteration before the launch usually ran */ n_plain < 4,
+                             c->dist2_max, normal_threshold, c->d_log, end_ops, closed ? &a : nullptr, /* rows_ahead: the iteration before the launch usually ran */ n_plain < 4,
                              (unsigned)c->barrier_units * launch::icp_tail_unit(), c->stream);
             it += n_tail;
         }
@@ -736,7 +737,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
         // finds none left gets one launch per iteration instead (no barrier, a few per cent slower) rather than a barrier that could
         // time out.  Reserved here, under the registry lock (the context itself joins the registry only when it is complete): two
         // threads creating contexts at once cannot overbook.  kfh_destroy gives the units back, also for a creation that fails.
-        // (KFH_ICP_TAIL_BLOCKS = 32 ... 256 asks for another width for every context, as long as units are left.)
+        // (KFH_ICP_TAIL_BLOCKS = 1 ... 256, rounded up to whole units of 32, asks for another width for every context, as long as units are left.)
         static const int width_env = [] { const char *e = getenv("KFH_ICP_TAIL_BLOCKS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 256) ? v : 0; }();
         const int unit = (int)launch::icp_tail_unit();
         std::lock_guard<std::mutex> lk(g_registry_mu);
@@ -781,7 +782,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     kfh_reset(c);
     launch::prepare_volume_division(c->volDim, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);   // one-off check, off the frame path
     launch::prepare_bilateral_division(e_delta, c->stream);
-    launch::prepare_sqrt_bound(dist_threshold, c->stream);         // the ICP association's length(diff) > dist_threshold (cpp:543)
+    c->dist2_max = launch::prepare_sqrt_bound(dist_threshold, c->stream);         // the ICP association's length(diff) > dist_threshold (cpp:543)
     if (const int verdict = launch::reduction_verified(c->stream); verdict != 1) {      // (fatal: every ICP sum of this backend goes through that reduction)
         g_last_error = verdict == 0 ? "kfh_create: the ICP block reduction failed its self-check on this device (k_verify_reduce)"
                                     : "kfh_create: the self-check of the ICP block reduction could not be run (HIP error: allocation, launch or wait)";
@@ -1160,6 +1161,21 @@ int kfh_read_profile(kfh_context *c, double ms_out[KFH_PROF_COUNT], uint64_t lau
     prof_collect(c);
     for (int p = 0; p < KFH_PROF_COUNT; ++p) { if (ms_out) ms_out[p] = c->prof_ms[p]; if (launches_out) launches_out[p] = c->prof_n[p]; }
     return KFH_OK;
+}
+
+// launches of a tracked frame's ICP loop as THIS context queues it (enqueue_tracking): per level the iterations with a launch of their
+// own plus one shared launch for the rest (tail_length: the schedule depends on how wide a shared launch the context was given at
+// creation), plus k_icp_final where no shared launch of level 0 closes the loop
+uint32_t kfh_icp_launches_per_frame(kfh_context *c) { Entry e_(c);
+    static const bool fold_env = [] { const char *e = getenv("KFH_ICP_TAIL_CLOSES"); return !(e && e[0] == '0'); }();
+    uint32_t n = 0;
+    bool closed = false;
+    for (int level = (int)c->iterations.size() - 1; level >= 0; --level) {
+        const int n_tail = tail_length(c, level);
+        n += (uint32_t)(c->iterations[level] - n_tail) + (n_tail > 0 ? 1u : 0u);
+        if (n_tail > 0 && level == 0 && fold_env) closed = true;
+    }
+    return n + (closed || n == 0 ? 0u : 1u);
 }
 
 uint64_t kfh_icp_iterations(kfh_context *c) { Entry e_(c); c->mirror_stale = true; refresh_mirror(c); return c->h_state->icp_iterations; }

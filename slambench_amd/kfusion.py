@@ -164,6 +164,10 @@ class Kfusion:
     def icp_iterations(self):
         return int(self.L.kfh_icp_iterations(self.h))
 
+    def icp_launches_per_frame(self):
+        """launches of a tracked frame's ICP loop as this context queues it"""
+        return int(self.L.kfh_icp_launches_per_frame(self.h))
+
     def icp_level_iterations(self):
         """executed ICP iterations by pyramid level (index 0 = full resolution)"""
         out = (C.c_uint64 * 8)()   # KFH_MAX_LEVELS

@@ -52,3 +52,20 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(ROOT, "include", f)
         if os.path.isfile(p):
             assert "orc_" not in open(p).read()
+
+
+def test_default_build_has_no_result_changing_switches():
+    """switches that change results (the stage probes of k_integrate, the parked probe paths) exist only in builds made
+    with an explicit -D flag; the forced barrier time-out is honoured only beside KFH_ENABLE_TEST_HOOKS=1.  The shipped library must not
+    even contain the probe switches' names (every getenv name is a string literal in the host code)."""
+    from slambench_amd import _capi, build
+    if not os.path.exists(_capi.LIB_PATH):
+        build.build_library()
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"KFH_INTEGRATE_DBG", b"KFH_INT_PROBE_STAGE", b"KFH_INT_PROBE_FROM", b"KFH_TAIL_PROBE", b"KFH_INT_SPECULATE"):
+        assert name not in blob, "the default build of libkfusion_hip.so reads %s" % name.decode()
+    assert b"KFH_ICP_TAIL_TIMEOUT_TICKS" in blob and b"KFH_ENABLE_TEST_HOOKS" in blob
+    src = open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_launch.hip")).read() if os.path.exists(
+        os.path.join(ROOT, "slambench_amd", "csrc", "kf_launch.hip")) else open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_kernels.hip")).read()
+    i = src.index('getenv("KFH_ICP_TAIL_TIMEOUT_TICKS")')
+    assert 'getenv("KFH_ENABLE_TEST_HOOKS")' in src[i - 200:i + 200], "the forced time-out must be gated by KFH_ENABLE_TEST_HOOKS"

@@ -187,7 +187,7 @@ def test_shared_late_iteration_launch_equals_one_launch_per_iteration(hip, kfmod
     k = list(stream.k)
     res = (128, 128, 128)
     runs = {}
-    for head in ("0", "4", "1", ""):      # 0: no tail launches; 1: every level's iterations 1.. share a launch; "": the default (4 on level 0, 3 above)
+    for head in ("0", "4", "1", ""):      # 0: no tail launches; 1: every level's iterations 1.. share a launch; "": the default (3 everywhere for the first context of a device, whose shared launch is 64 workgroups wide; 4 on level 0 for further ones)
         if head:
             monkeypatch.setenv("KFH_ICP_TAIL_HEAD", head)
         else:

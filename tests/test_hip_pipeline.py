@@ -325,7 +325,7 @@ print("FAILED_FRAME", raised[0])
 
 def test_barrier_timeout_fails_the_frame(hip, tmp_path):
     """a workgroup of k_icp_tail that gives up at the grid barrier carried on with stale sums and the frame was still
-    logged as valid.  With the time-out forced to zero (KFH_ICP_TAIL_TIMEOUT_TICKS=0, own process: the knob is read once) the
+    logged as valid.  With the time-out forced to zero (KFH_ICP_TAIL_TIMEOUT_TICKS=0 beside KFH_ENABLE_TEST_HOOKS=1, own process: the knob is read once) the
     frame must fail everywhere: pose rolled back on the device, KFH_ERR_BARRIER from kfh_tracking and the getters, sticky
     kfh_get_error, and the drop-in driver exits non-zero."""
     import os
@@ -334,7 +334,7 @@ def test_barrier_timeout_fails_the_frame(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "forced.py"
     script.write_text(FORCED_TIMEOUT % root)
-    env = dict(os.environ, KFH_ICP_TAIL_TIMEOUT_TICKS="0")
+    env = dict(os.environ, KFH_ICP_TAIL_TIMEOUT_TICKS="0", KFH_ENABLE_TEST_HOOKS="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "FAILED_FRAME" in r.stdout and "timed out at the ICP grid barrier" in r.stderr
