@@ -344,10 +344,17 @@ def main(argv=None):
         # launched plainly with --gpus N: this process has made no torch / GPU call; the ranks run in a child process
         raise SystemExit(spawn_ranks(args, argv))
 
-    import torch
-    from slambench_amd import multi
-
+    # each rank next to its GPU: confined to the cores of the GPU's NUMA node BEFORE torch or HIP is loaded, so that every thread
+    # and every pinned buffer of the rank is made there (slambench_amd/affinity.py; no numactl wrapper)
+    from slambench_amd import affinity, multi
     world, rank, local_rank = multi.env_rank()
+    one_device = os.environ.get("KFH_BENCH_ONE_DEVICE") == "1"     # rehearsal on a one-GPU box: the ranks side by side on cuda:0, collectives on the host
+    pin = {"pinned": False, "cpus": None, "numa_node": None, "why": "dry run"} if args.dry_collectives else \
+        affinity.pin_to_gpu_numa_node(0 if one_device else local_rank)
+    print("bench.py: rank %d: cpu affinity %s (%s%s)" % (rank, pin["cpus"], "pinned to NUMA node %s, " % pin["numa_node"] if pin["pinned"] else "not pinned: ", pin["why"]), file=sys.stderr)
+
+    import torch
+
     if world != args.gpus:
         # never measure fewer GPUs than were asked for (nor more): the record would carry the wrong n_gpus
         print("bench.py: --gpus %d but the torch.distributed environment holds WORLD_SIZE=%d: start it as `python bench.py --gpus %d` "
@@ -355,7 +362,6 @@ def main(argv=None):
         raise SystemExit(2)
     dry = args.dry_collectives
     backend = "gloo" if dry else os.environ.get("KFH_BENCH_BACKEND", "nccl")
-    one_device = os.environ.get("KFH_BENCH_ONE_DEVICE") == "1"     # rehearsal on a one-GPU box: the ranks side by side on cuda:0, collectives on the host
     if not dry:
         have = torch.cuda.device_count()
         need = 1 if one_device else world
@@ -363,7 +369,12 @@ def main(argv=None):
             print("bench.py: rank %d: --gpus %d needs %d visible GPU(s), this node shows %d" % (rank, args.gpus, need, have), file=sys.stderr)
             raise SystemExit(2)
     dist = None
-    if world > 1:
+    # KFH_BENCH_FORCE_GROUP=1: a process group even for one rank (rehearsal: init_process_group("nccl", device_id=...), the CUDA-tensor
+    # all-reduces and destroy_process_group run once on a one-GPU box before an 8-GPU node sees them, tests/test_hip_bench_ranks.py)
+    force_group = world == 1 and os.environ.get("KFH_BENCH_FORCE_GROUP") == "1"
+    if force_group:
+        os.environ.setdefault("MASTER_PORT", "29555"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+    if world > 1 or force_group:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
@@ -380,6 +391,7 @@ def main(argv=None):
         local_rank = 0
     coll_device = "cuda" if (backend == "nccl" and not dry) else "cpu"
     S = Session(torch, dist, world, rank, local_rank, coll_device, dry)
+    S.pin, S.backend = pin, (backend if dist is not None else None)
     try:
         run(S, args, multi)
     finally:
@@ -675,6 +687,16 @@ def run(S, args, multi):
     seen = multi.ranks_seen(S.dist, S.coll_device)
     if seen != args.gpus:
         raise SystemExit("bench.py: the all-reduce over the process group counted %d ranks, --gpus says %d" % (seen, args.gpus))
+    # who ran what and where, by rank: trajectory index of the rank's stream (4 distinct trajectories, reused x2 on 8 GPUs:
+    # BASELINE.json configs[4]) and the host cores the rank was confined to
+    pin = getattr(S, "pin", None) or {"pinned": False, "cpus": None, "numa_node": None, "why": None}
+    from slambench_amd import affinity as _aff
+    rows = multi.gather_rows([multi.stream_variant(S.rank), 1.0 if pin["pinned"] else 0.0, -1.0 if pin["numa_node"] is None else pin["numa_node"],
+                              len(_aff.parse_cpulist(pin["cpus"])) if pin["cpus"] else 0], S.dist, S.coll_device)
+    placement = {"trajectories": [int(r[0]) for r in rows], "ranks_pinned": int(sum(r[1] for r in rows)),
+                 "numa_node_by_rank": [None if r[2] < 0 else int(r[2]) for r in rows], "cpus_by_rank": [int(r[3]) for r in rows],
+                 "rank0_cpu_affinity": pin["cpus"], "rank0_note": pin["why"], "collective_backend": getattr(S, "backend", None),
+                 "scaling_note": "weak scaling of independent RGB-D streams: one stream and one TSDF volume per GPU, no per-frame exchange"}
     head = measure(S, args, multi, args.config, args.steps, args.warmup, True)
     extra_names = args.extra_configs
     if extra_names is None:
@@ -702,7 +724,7 @@ def run(S, args, multi):
         out = {"metric": "DRY RUN (--dry-collectives): rendezvous, barriers and all-reduces only, no frame was computed", "value": None,
                "unit": "frames/s", "n_gpus": S.world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True,
-               "config": {"workload": args.config}, "timed_s": head["timed_s"], "frames_all_ranks": head["frames"],
+               "config": {"workload": args.config}, "timed_s": head["timed_s"], "frames_all_ranks": head["frames"], "placement": placement,
                "configs": {k: compact(v) for k, v in extra.items()}}
         print(json.dumps(out))
         return
@@ -728,6 +750,7 @@ def run(S, args, multi):
         "roofline": roof.get(dominant),
         "roofline_other": {k: v for k, v in roof.items() if k != dominant},
         "cpu_baseline": head["cpu_baseline"],
+        "placement": placement,
         "configs": {k: compact(v) for k, v in extra.items()},
     }
     print(json.dumps(out))

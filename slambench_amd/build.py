@@ -18,7 +18,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkfusion_hip.so")
 BENCH_BIN = os.path.join(HERE, "kfusion-benchmark-hip")
 
-HIP_SOURCES = ["kf_kernels.hip", "kf_pipeline.hip"]
+HIP_SOURCES = ["kf_preprocess.hip", "kf_icp.hip", "kf_integrate.hip", "kf_raycast.hip", "kf_render.hip", "kf_launch.hip", "kf_pipeline.hip"]
+HIP_HEADERS = ["kf_math.h", "kf_kernels.h", "kf_dev.h"]
+OBJ_DIR = os.path.join(HERE, "csrc", "build")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -37,16 +39,37 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("kf_math.h", "kf_kernels.h")] + [os.path.join(ROOT, "include", "kfusion_hip.h")]
-    if not force and _newer(LIB, deps):
-        return LIB
-    extra = os.environ.get("KFH_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DKFH_ICP_WAVES_PER_SIMD=8)
-    cmd = [hipcc()] + HIP_FLAGS + extra + ["-shared", "-I", os.path.join(ROOT, "include")] + srcs + ["-o", LIB]
+def _compile(args):
+    cmd, verbose = args
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """One object per translation unit (compiled in parallel, only the stale ones), then one link: a change to one kernel file
+    recompiles that file."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    hdrs = [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "kfusion_hip.h")]
+    extra = os.environ.get("KFH_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (e.g. -DKFH_ICP_WAVES_PER_SIMD=8)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    flags_text = " ".join(HIP_FLAGS + extra)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_text:
+        force = True            # other flags than the objects were built with
+    objs, jobs = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not _newer(obj, [src] + hdrs):
+            jobs.append(([hipcc()] + HIP_FLAGS + extra + ["-c", "-I", os.path.join(ROOT, "include"), src, "-o", obj], verbose))
+    if not jobs and _newer(LIB, objs):
+        return LIB
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(_compile, jobs))
+    open(stamp, "w").write(flags_text)
+    _compile(([hipcc()] + HIP_FLAGS + ["-shared"] + objs + ["-o", LIB], verbose))
     return LIB
 
 

@@ -91,7 +91,7 @@ struct ControlArgs {
     float vol_dim[3];    // OP_INTEG_BEGIN: extent of the volume (integrate_bounds)
 };
 
-// Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_kernels.hip, "side jobs"):
+// Input-only work of the NEXT frame that rides on an ICP launch of the current one (kf_icp.hip, "side jobs"):
 // a range of 32x8 bilateral tiles or of 32x32 pyramid tiles.  All buffers belong to the other half of the double buffer.
 struct SideWork {
     enum Kind { NONE = 0, BILATERAL = 1, PYRAMID = 2, RAY_ORDER = 3 };
@@ -118,7 +118,7 @@ struct SideWork {
     unsigned order_mode;              // 0: raycast tiles, 1: integrate blocks (ray_tiles_x = count, ray_tiles_y = 1)
 };
 
-// OP_TRACK_BEGIN of the next queued frame, carried by a raycast launch (kf_kernels.hip, SkipGrid::next_state)
+// OP_TRACK_BEGIN of the next queued frame, carried by a raycast launch (kf_raycast.hip, SkipGrid::next_state)
 struct NextTrackBegin { DevState *state; float k[4]; unsigned frame, tracking_rate; };
 
 namespace launch {

@@ -668,6 +668,10 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
         g_last_error = "kfh_create: an x-y plane of the volume must hold fewer than 2^24 voxels (24-bit multiplies in the voxel addressing)";
         return nullptr;
     }
+    if ((unsigned long long)width * height >= (1ull << 26)) {
+        g_last_error = "kfh_create: the computation image must hold fewer than 2^26 pixels (32-bit pixel addressing)";
+        return nullptr;
+    }
     if (device >= 0 && !HIP_TRY(hipSetDevice(device))) return nullptr;
     kfh_context *c = new kfh_context();
     HIP_TRY(hipGetDevice(&c->device));

@@ -82,3 +82,17 @@ def ranks_seen(dist=None, device="cpu") -> int:
     t = torch.ones(1, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(round(t.item()))
+
+
+def gather_rows(row, dist=None, device="cpu"):
+    """Every rank's small numeric row, in rank order, on every rank: one all-reduce (sum) of a world x len(row) matrix in which a rank
+    fills its own line - the collective the bench already relies on, not a pickling all_gather_object."""
+    row = [float(v) for v in row]
+    if dist is None or not dist.is_initialized():
+        return [row]
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros((world, len(row)), dtype=torch.float64, device=device)
+    t[rank] = torch.tensor(row, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().tolist()

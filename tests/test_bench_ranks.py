@@ -72,3 +72,57 @@ def test_more_gpus_than_the_node_has_fails_loudly():
                          timeout=300, env=_env(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""), cwd=ROOT)
     assert out.returncode == 2, out.stdout[-500:] + out.stderr[-2000:]
     assert "needs 1 visible GPU(s)" in out.stderr and not out.stdout.strip()
+
+
+def test_eight_ranks_dry_as_the_scaling_run_will_launch_them():
+    """VERDICT r4 #6b: the N = 8 shape of BASELINE.json configs[4] - eight ranks through the real main() (gloo, no frames): the world
+    size, the ranks the collective saw, and the trajectory each rank runs (4 distinct ones, reused x2)."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-collectives", "--extra-configs", "cfg3"],
+                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    j = _json_line(out.stdout)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["scaling"] == "weak"
+    assert j["placement"]["trajectories"] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert j["frames_all_ranks"] == 8 * 2 and j["configs"]["cfg3"]["frames"] == 8 * 40
+    assert "independent" in j["placement"]["scaling_note"]
+
+
+def test_numa_pinning_reads_the_topology(tmp_path, monkeypatch):
+    """slambench_amd/affinity.py on a fake sysfs: two sockets, four GPUs in KFD order behind two CPU nodes, a visibility filter, a host
+    without NUMA information - and on this machine's real sysfs, whatever it holds, it must return a record and never raise."""
+    from slambench_amd import affinity
+    kfd, pci, node = tmp_path / "kfd", tmp_path / "pci", tmp_path / "node"
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    sockets = [allowed[:half], allowed[half:] or allowed[:half]]
+    for i, cpus in enumerate(sockets):
+        (node / ("node%d" % i)).mkdir(parents=True)
+        (node / ("node%d" % i) / "cpulist").write_text(affinity.format_cpulist(cpus) + "\n")
+    props = ["simd_count 0\nlocation_id 0\ndomain 0\n"] * 2
+    bdfs = []
+    for g in range(4):
+        bus = 0x10 + 0x20 * g
+        props.append("simd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        bdf = "0000:%02x:00.0" % bus
+        bdfs.append(bdf)
+        (pci / bdf).mkdir(parents=True)
+        (pci / bdf / "numa_node").write_text("%d\n" % (g // 2))
+    for i, text in enumerate(props):
+        (kfd / str(i)).mkdir(parents=True)
+        (kfd / str(i) / "properties").write_text(text)
+    roots = dict(kfd_root=str(kfd), pci_root=str(pci))
+    assert affinity.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and affinity.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    assert [affinity.gpu_numa_node(r, {}, **roots)[0] for r in range(4)] == [0, 0, 1, 1]
+    assert affinity.gpu_numa_node(0, {"HIP_VISIBLE_DEVICES": "3,0"}, **roots) == (1, bdfs[3])
+    assert affinity.gpu_numa_node(5, {}, **roots)[0] is None and affinity.gpu_numa_node(0, {"HIP_VISIBLE_DEVICES": "GPU-abc"}, **roots)[0] is None
+    (pci / bdfs[0] / "numa_node").write_text("-1\n")
+    assert affinity.gpu_numa_node(0, {}, **roots)[0] is None
+    try:
+        rec = affinity.pin_to_gpu_numa_node(3, {}, node_root=str(node), **roots)
+        assert rec["pinned"] and rec["numa_node"] == 1 and affinity.parse_cpulist(rec["cpus"]) == sorted(set(sockets[1]))
+        assert sorted(os.sched_getaffinity(0)) == sorted(set(sockets[1]))
+    finally:
+        os.sched_setaffinity(0, allowed)
+    rec = affinity.pin_to_gpu_numa_node(0)            # the real sysfs of this machine: a record, never an exception
+    assert set(rec) == {"pinned", "cpus", "numa_node", "why"}
+    os.sched_setaffinity(0, allowed)

@@ -65,7 +65,6 @@ def test_default_build_has_no_result_changing_switches():
     for name in (b"KFH_INTEGRATE_DBG", b"KFH_INT_PROBE_STAGE", b"KFH_INT_PROBE_FROM", b"KFH_TAIL_PROBE", b"KFH_INT_SPECULATE"):
         assert name not in blob, "the default build of libkfusion_hip.so reads %s" % name.decode()
     assert b"KFH_ICP_TAIL_TIMEOUT_TICKS" in blob and b"KFH_ENABLE_TEST_HOOKS" in blob
-    src = open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_launch.hip")).read() if os.path.exists(
-        os.path.join(ROOT, "slambench_amd", "csrc", "kf_launch.hip")) else open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_kernels.hip")).read()
+    src = open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_icp.hip")).read()
     i = src.index('getenv("KFH_ICP_TAIL_TIMEOUT_TICKS")')
     assert 'getenv("KFH_ENABLE_TEST_HOOKS")' in src[i - 200:i + 200], "the forced time-out must be gated by KFH_ENABLE_TEST_HOOKS"

@@ -1,7 +1,7 @@
 """Round-4 GPU tests: the partition of an ICP level that is larger than one pass over the blocks.
 
 A level of more than 256 x 1024 pixels is walked in full passes over the blocks plus a remainder that is dealt in 64-pixel chunks to
-the blocks' WAVES (kf_kernels.hip icp_track_block); at 640x480 the remainder is a whole number of chunks.  Here: sizes whose
+the blocks' WAVES (kf_icp.hip icp_track_block); at 640x480 the remainder is a whole number of chunks.  Here: sizes whose
 remainder ends in a PARTIAL chunk and reaches the blocks' second, third and fourth waves."""
 import numpy as np
 import pytest

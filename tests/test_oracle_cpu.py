@@ -289,7 +289,7 @@ def test_squared_length_bound_of_the_icp_distance_test():
 def test_row_of_a_pixel_by_a_reciprocal_multiplication():
     """The HIP ICP association needs the row of pixel p on a coarse level (the result map keeps the full-resolution row stride,
     cpp:512) and computes it as (unsigned)(((float)p + 0.5f) * RN(1 / inW)) while the level has at most 2^22 pixels
-    (kf_kernels.hip make_icp_args / icp_track_block), instead of an integer division by a run-time value.  The same float32
+    (kf_icp.hip make_icp_args / icp_track_block), instead of an integer division by a run-time value.  The same float32
     operations in numpy, for EVERY pixel below 2^22 of widths of every kind (powers of two, odd, prime, the pyramid levels of the
     benchmark sizes): equal to p // inW."""
     f32 = np.float32
