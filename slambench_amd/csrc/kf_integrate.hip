@@ -29,17 +29,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct ColumnState { v2f a, b; float cy, cz; };   // (pos.x, pos.y), (pos.z, cam.x), cam.y, cam.z (cz unused when KZ)
 
-// conservative "projects outside the image on this side" bits; valid only where cam.z > 0.
-// lo = -(0.5 + margin), wlim/hlim = size - 0.5 + margin:  x/z < lo => x/z + 0.5 < 0;  x/z > wlim => x/z + 0.5 > W - 1.
-__device__ __forceinline__ unsigned outside_bits(float camx, float camy, float camz, float lo, float wlim, float hlim) {
-    unsigned m = 0;
-    m |= (camx < lo * camz) ? 1u : 0u;
-    m |= (camx > wlim * camz) ? 2u : 0u;
-    m |= (camy < lo * camz) ? 4u : 0u;
-    m |= (camy > hlim * camz) ? 8u : 0u;
-    return m;
-}
-
 #ifndef KFH_INT_BX
 #define KFH_INT_BX 32
 #endif
@@ -74,9 +63,11 @@ template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) 
 #else
 #define KFH_INT_PROBE(bit) false
 #endif
-#ifndef KFH_INT_LEAN
-#define KFH_INT_LEAN 1      // the select-based detailed pass (round 5); 0 = round 4's branchy form, kept for the A/B of profiles/r05_sweeps.md
-#endif
+// (plain global stores: dirty in the XCD's L2 until the launch's closing write-back.  Round 5 measured the alternatives as raw buffer
+// stores with aux bits, profiles/r05_ab_store_aux.txt: sc0 sc1 - written through as issued - 97.2 -> 103.0 us at 512^3, nt 97.9, aux 0 98.6.)
+__device__ __forceinline__ void store_voxel(short2 *vol, unsigned byte_offset, unsigned value) {
+    *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(vol) + byte_offset) = value;
+}
 #ifndef KFH_INTEGRATE_WAVES_PER_SIMD
 #define KFH_INTEGRATE_WAVES_PER_SIMD 5      // occupancy floor handed to the register allocator (5 = at most 96 VGPRs)
 #endif
@@ -160,8 +151,6 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             for (; z < z0; ++z) march_step<KZ>(S, da, db, dc);
         }
-        const size_t plane = (size_t)sx * sy;
-        short2 *cell = vol + x + (size_t)y * sx + (size_t)z0 * plane;
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
         // per-voxel test: the very floats the reference divides, 0.1 px of margin covers the rounding of the product.
         // batch test: interior voxels are the endpoints' interpolation plus at most IB roundings of the running sums, each
@@ -169,8 +158,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         // 0.2 of the 0.25 px margin.  max|cam.x| over the volume is bounded per launch (IntegrateParams::cam_bound, from the
         // intrinsics and the camera position): where the bound fails - huge intrinsics or volumes - no batch is rejected
         // on its end voxels and every voxel takes the reference tests.
-        const bool batch_ok = (float)IB * 5.9604645e-8f * P.cam_bound < 0.2f * 0.05f;
-        const float wlim = (float)W - 0.4f, hlim = (float)H - 0.4f;
+        const bool batch_ok = (float)(IB + 1) * 5.9604645e-8f * P.cam_bound < 0.2f * 0.05f;
         const float wlim_b = (float)W - 0.25f, hlim_b = (float)H - 0.25f;
         const float ptol = 2e-6f * (float)(W > H ? W : H);
         // (voxel byte offsets in 32 bits: the launcher refuses volumes above 2^30 voxels, sizes_addressable)
@@ -179,35 +167,40 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         const float wclamp = (float)W + 0.5f, hclamp = (float)H + 0.5f;
         // (the batch counter is the same in every lane - a lane whose chunk is out sits the loop out - so that "is voxel i part of
         // this batch" is a scalar question)
+        // End-voxel test of a batch: the four signed distances of an end point from the image's sides - negative = outside on that
+        // side, with the quarter-pixel margin - are kept from one batch to the next: a batch is judged on its first voxel and the
+        // first voxel of the NEXT batch (one voxel more than it holds, which the bound above allows for), so every end point is
+        // evaluated once; "both outside on the same side" is max(first, next) < 0 for some side.
+        struct EndPoint { float l, r, t, b, cz, z; };
+        auto end_point = [&](const ColumnState &E) {
+            const float cz = cam_z<KZ>(E);
+            EndPoint e;
+            e.l = __builtin_fmaf(0.75f, cz, E.b.y); e.r = __builtin_fmaf(wlim_b, cz, -E.b.y);
+            e.t = __builtin_fmaf(0.75f, cz, E.cy); e.b = __builtin_fmaf(hlim_b, cz, -E.cy);
+            e.cz = cz; e.z = E.b.x;
+            return e;
+        };
+        EndPoint ep = end_point(S);
         if (!chunk_out)
-        for (unsigned zb = z0; zb < z1; zb += IB, cell += (size_t)IB * plane, voff += (unsigned)IB * plane4) {
+        for (unsigned zb = z0; zb < z1; zb += IB, voff += (unsigned)IB * plane4) {
             const unsigned nb = (z1 - zb) < (unsigned)IB ? (z1 - zb) : (unsigned)IB;
             const ColumnState first = S;
-            ColumnState last;
-            // advance over the batch; `last` is the state of its final voxel, S the state of the next batch's first
+            // advance over the batch: S becomes the state of the next batch's first voxel
             if (nb == (unsigned)IB) {   // whole batch (all but possibly the last of a chunk): straight-line packed adds
 #pragma unroll
-                for (int i = 0; i < IB - 1; ++i) { march_step<KZ>(S, da, db, dc); }
-                last = S;
-                march_step<KZ>(S, da, db, dc);
+                for (int i = 0; i < IB; ++i) { march_step<KZ>(S, da, db, dc); }
             } else {
-                last = S;
-                for (unsigned i = 0; i < nb; ++i) {
-                    last = S;
-                    march_step<KZ>(S, da, db, dc);
-                }
+                for (unsigned i = 0; i < nb; ++i) march_step<KZ>(S, da, db, dc);
             }
             {
-                const float z_f = first.b.x, z_l = last.b.x;          // pos.z
-                const float cz_f = cam_z<KZ>(first), cz_l = cam_z<KZ>(last);
-                const bool behind = z_f < 0.00005f && z_l < 0.00005f;
-                bool outside = false;
-                if (batch_ok && cz_f > 0.05f && cz_l > 0.05f)
-                    outside = (outside_bits(first.b.y, first.cy, cz_f, -0.75f, wlim_b, hlim_b) &
-                               outside_bits(last.b.y, last.cy, cz_l, -0.75f, wlim_b, hlim_b)) != 0u;
+                const EndPoint en = end_point(S);
+                const bool behind = __builtin_fmaxf(ep.z, en.z) < 0.00005f;
+                const float side = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ep.l, en.l), __builtin_fmaxf(ep.r, en.r)),
+                                                   __builtin_fminf(__builtin_fmaxf(ep.t, en.t), __builtin_fmaxf(ep.b, en.b)));
+                const bool outside = batch_ok && __builtin_fminf(ep.cz, en.cz) > 0.05f && side < 0.f;
+                ep = en;
                 if (behind || outside || KFH_INT_PROBE(1)) continue;
             }
-#if KFH_INT_LEAN
             // ---- detailed pass over the batch, replaying the additions from its first voxel: straight-line code with selects.  The
             // heaviest waves - every batch in the frustum and near the surface - are what the launch waits for, and a lone wave issues one
             // instruction per ~8 cycles whatever its kind: round 4's form of this pass spent ~20 scalar instructions per voxel on nested
@@ -282,9 +275,11 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 // Free space in front of the surface that has only ever been free space: 32766 * kShort2Float is 1.0f exactly, so the
                 // running average (w * 1 + 1) / (w + 1) is 1 and the stored short 32766 again, for every weight; only the weight moves
                 // (the same float operations as below), and a saturated voxel is stored back unchanged - i.e. not at all.
-                if (t_[i] >= mu && cx16 == 32766) {
+                // (Taken when every lane of the wave that updates voxel i is of that kind - the usual case away from the surface;
+                // otherwise all of them go through the formula, which gives those lanes the same bits.)
+                if (__builtin_amdgcn_ballot_w64(!(t_[i] >= mu && cx16 == 32766)) == 0ull) {
                     const short w16 = (short)fmin_h((float)cw16 + 1, maxweight);
-                    if (w16 != cw16) *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(vol) + (voff + (unsigned)i * plane4)) = 32766u | ((unsigned)(unsigned short)w16 << 16);
+                    if (w16 != cw16) store_voxel(vol, voff + (unsigned)i * plane4, 32766u | ((unsigned)(unsigned short)w16 << 16));
                     ++updated;
                     continue;
                 }
@@ -301,103 +296,11 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
                 w = fmin_h(w + 1, maxweight);
                 const short ts = (short)(tsdf * 32766.0f);
-                *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(vol) + (voff + (unsigned)i * plane4)) = (unsigned)(unsigned short)ts | ((unsigned)(unsigned short)(short)w << 16);
+                store_voxel(vol, voff + (unsigned)i * plane4, (unsigned)(unsigned short)ts | ((unsigned)(unsigned short)(short)w << 16));
                 if (skip_flags && ts < kSkipShortFwd && cx16 >= kSkipShortFwd)   // flags are sticky: first crossing only
                     mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
                 ++updated;
             }
-#else
-            // detailed pass over the batch, replaying the additions from its first voxel
-            ColumnState T = first;
-            unsigned live = 0;            // bit i: voxel zb+i projects into the image
-            unsigned pix[IB];
-#pragma unroll
-            for (int i = 0; i < IB; ++i) {
-                if ((unsigned)i < nb) {
-                    const float posz = T.b.x, cx = T.b.y, cy = T.cy, cz = cam_z<KZ>(T);
-                    if (!(posz < 0.0001f)) {                                       // cpp:647
-                        const bool far_out = cz > 0.f && outside_bits(cx, cy, cz, -0.6f, wlim, hlim) != 0u;
-                        if (!far_out) {
-                            // cpp:649-654 needs only the comparisons with 0 / W-1 / H-1 and the integer part of
-                            // fl(fl(c/z) + 0.5).  c * rcp(z) is within 3 ulp of fl(c/z), i.e. within 3.6e-7 * max(W,H)
-                            // pixels wherever those outcomes are undecided; unless it lands within `ptol` (5x that) of
-                            // an integer it gives the same decisions and the same integer.  The IEEE divisions run
-                            // only for those rare pixels.
-                            const float rz = __builtin_amdgcn_rcpf(cz);
-                            float px = cx * rz + 0.5f, py = cy * rz + 0.5f;
-                            const float nx = rintf(px), ny = rintf(py);
-                            if (fabsf(px - nx) < ptol || fabsf(py - ny) < ptol || !(fabsf(px) < 65536.f) || !(fabsf(py) < 65536.f)) {
-                                px = cx / cz + 0.5f;
-                                py = cy / cz + 0.5f;
-                            }
-                            if (!(px < 0 || px > wm1 || py < 0 || py > hm1)) {     // cpp:651-653
-                                live |= 1u << i;
-                                pix[i] = (unsigned)px + (unsigned)py * W;
-                            }
-                        }
-                    }
-                    march_step<KZ>(T, da, db, dc);
-                }
-            }
-            ++work;
-            if (!live || KFH_INT_PROBE(2)) continue;
-            float d[IB];
-#pragma unroll
-            for (int i = 0; i < IB; ++i)
-                if (live & (1u << i)) d[i] = depth[pix[i]];
-            // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
-            unsigned need = 0;
-            float t_[IB];
-            float camz_i = cam_z<KZ>(first);  // cam.z of voxel i, replayed like the positions below
-            const float dz_step = KZ ? db.x : dc.y;
-#pragma unroll
-            for (int i = 0; i < IB; ++i, camz_i += dz_step) {
-                if (!(live & (1u << i))) continue;
-                if (d[i] == 0) continue;                                           // cpp:655
-                const float t = d[i] - camz_i;
-                if (t <= -mu) continue;
-                t_[i] = t;
-                need |= 1u << i;
-            }
-            if (!need || KFH_INT_PROBE(4)) continue;
-            work += 4;
-            short2 c[IB];
-#pragma unroll
-            for (int i = 0; i < IB; ++i)
-                if (need & (1u << i)) c[i] = cell[(size_t)i * plane];
-#if KFH_INT_PROBES
-            if (KFH_INT_PROBE(16)) {      // (the loads stay: each fetched voxel is "used")
-#pragma unroll
-                for (int i = 0; i < IB; ++i)
-                    if (need & (1u << i)) asm volatile("" : : "v"(*reinterpret_cast<const int *>(&c[i])));
-                continue;
-            }
-#endif
-            // the world position of a band voxel is replayed from the batch's first state (3 packed adds per voxel) instead
-            // of being kept in 24 registers across the two memory round trips above
-            ColumnState R = first;
-#pragma unroll
-            for (int i = 0; i < IB; ++i, R.a += da, R.b += db) {
-                if (!(need & (1u << i))) continue;
-                float sdf;
-                if (t_[i] >= mu) {
-                    sdf = 1.f;
-                } else {
-                    const float rx = R.a.x, ry = R.a.y, rz = R.b.x;
-                    const float diff = t_[i] * sqrtf(1 + sq(rx / rz) + sq(ry / rz));
-                    if (!(diff > -mu)) continue;
-                    sdf = fmin_h(1.f, diff / mu);
-                }
-                float tsdf = c[i].x * kShort2Float, w = c[i].y;
-                tsdf = clamp_h((w * tsdf + sdf) / (w + 1), -1.f, 1.f);
-                w = fmin_h(w + 1, maxweight);
-                const short ts = (short)(tsdf * 32766.0f);
-                cell[(size_t)i * plane] = make_short2(ts, (short)w);
-                if (skip_flags && ts < kSkipShortFwd && c[i].x >= kSkipShortFwd)   // flags are sticky: first crossing only
-                    mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
-                ++updated;
-            }
-#endif
         }
     }
     // two of three waves examined nothing (their chunks lie outside the frustum): nothing to add to the cost table or the

@@ -116,6 +116,11 @@ struct kfh_context {
     int q_slot = 0, q_last = -1;
     DevState *h_state = nullptr;
     uchar4 *h_render[3] = {nullptr, nullptr, nullptr};
+    // the vertex / normal maps hold a raycast of the volume AS IT IS (nothing has integrated into, reset or overwritten it since), made
+    // with these march parameters: renderVolume may shade the rays that hit from them (launch::render_volume, `seen`)
+    bool ray_maps_fresh = false;
+    float ray_maps_largestep = 0.f;
+    uchar4 *h_render_dev[3] = {nullptr, nullptr, nullptr};     // the same pinned staging buffers as the device sees them (render kernels of queued frames write there)
     std::vector<PendingCopy> pending;
     // optional HIP-event timing of pipeline phases (kfh_set_profiling)
     unsigned prof_mask = 0;
@@ -498,6 +503,7 @@ static void enqueue_integrate(kfh_context *c, float mu) {
         launch::integrate_order(c->d_int_order, c->d_int_cost, c->int_blocks, c->stream);
         c->int_order_stale = false;
     }
+    c->ray_maps_fresh = false;
     prof_begin(c, KFH_PROF_INTEGRATE);
     launch::integrate(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim, c->d_floatDepth, c->W, c->H,
                       &c->d_state->integ, mu, maxweight, &c->d_state->integrate_updated, c->use_skip ? c->d_skip : nullptr,
@@ -524,6 +530,7 @@ static void enqueue_raycast(kfh_context *c, float mu, const NextFrameWork *next 
                     &c->d_state->ray, nearPlane, farPlane, c->step, 0.75f * mu, c->use_skip ? c->d_skip : nullptr, c->d_ray_order,
                     c->d_ray_cost, next ? &nb : nullptr, c->stream);
     c->ray_order_stale = launch::ray_reorder_enabled();
+    c->ray_maps_fresh = true; c->ray_maps_largestep = 0.75f * mu;      // (whether the launch's device-side gate let it run is RayParams::enabled, which the render kernel reads)
     prof_end(c, KFH_PROF_RAYCAST);
 }
 
@@ -770,6 +777,7 @@ static kfh_context *create_common(uint32_t width, uint32_t height, const uint32_
     for (int i = 0; i < 3; ++i) {
         ok &= HIP_TRY(hipMalloc(&c->d_render[i], P * sizeof(uchar4)));
         ok &= HIP_TRY(hipHostMalloc(&c->h_render[i], P * sizeof(uchar4), hipHostMallocDefault));
+        if (ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_render_dev[i]), c->h_render[i], 0) != hipSuccess) { (void)hipGetLastError(); c->h_render_dev[i] = nullptr; }
     }
     ok &= HIP_TRY(hipHostMalloc(&c->h_state, sizeof(DevState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) ok &= HIP_TRY(hipEventCreateWithFlags(&c->input_done[i], hipEventDisableTiming));
@@ -874,6 +882,7 @@ void kfh_destroy(kfh_context *c) {
 void kfh_reset(kfh_context *c) { Entry e_(c);
     flush_frame(c);
     if (c->error == KFH_ERR_BARRIER) c->error = KFH_OK;   // a new sequence on a fresh volume: the failed frame is history
+    c->ray_maps_fresh = false;
     launch::init_volume(c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     HIP_TRY(hipMemsetAsync(c->d_skip, 0, launch::skip_grid_bytes(c->volRes[0], c->volRes[1], c->volRes[2]), c->stream));
 }
@@ -1009,27 +1018,49 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
     return c->error;   // KFH_OK, or what an EARLIER frame of this context left: queued frames report late (kfh_get_error after a sync is exact)
 }
 
-static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, uint32_t h) {
-    const size_t bytes = (size_t)w * h * sizeof(uchar4);
-    // Callers of the phase API (the benchmark driver) synchronise right after the renders: the image goes straight into their
-    // (pageable) buffer - the runtime returns once it is there - instead of through pinned staging plus a host copy at the
-    // next synchronisation (rendering column of the driver 205 -> 122 us per frame).  Callers that queue frames
-    // (kfh_compute_frame) keep the asynchronous staged copy, which does not stall their queue (KFH_RENDER_DIRECT=0/1 forces either).
+// Where a render kernel writes, and how the image reaches the caller's buffer:
+//  * phase API (the benchmark driver, which synchronises right after the renders): device buffer, then one copy straight into the
+//    caller's (pageable) buffer - the runtime returns once it is there (rendering column of the driver 205 -> 122 us per frame);
+//  * queued frames (kfh_compute_frame): device buffer, an asynchronous copy into pinned staging in the compute stream, and the host
+//    moves the image into the caller's buffer at the next synchronisation - the queue is not stalled.  (Round 5 measured the render
+//    kernels writing the image into the pinned buffer themselves, KFH_RENDER_ZEROCOPY=1: 4-byte stores over PCIe, 2.7 MB per frame at
+//    ~16 GB/s - fps_total 2780 against 3430 with the copy engine, profiles/r05_sweeps.md; the switch stays for the record, off.)
+//    KFH_RENDER_DIRECT=0/1 forces staged / direct.
+static bool render_is_direct(const kfh_context *c) {
     static const int direct_env = [] { const char *e = getenv("KFH_RENDER_DIRECT"); return e ? atoi(e) : -1; }();
-    if (direct_env >= 0 ? direct_env != 0 : !c->queued_api) {
-        for (size_t i = 0; i < c->pending.size();)
-            if (c->pending[i].dst == out) c->pending.erase(c->pending.begin() + i); else ++i;
-        HIP_TRY(hipMemcpyAsync(out, c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
-        return;
-    }
-    // one staging buffer per render: an earlier image of the same kind still waiting for ANOTHER destination is delivered first
+    return direct_env >= 0 ? direct_env != 0 : !c->queued_api;
+}
+static bool render_zero_copy(const kfh_context *c, int slot) {
+    static const bool on = [] { const char *e = getenv("KFH_RENDER_ZEROCOPY"); return e && e[0] == '1'; }();      // off: measured slower, see above
+    return on && !render_is_direct(c) && c->h_render_dev[slot] != nullptr;
+}
+// one staging buffer per render: an earlier image of the same kind still waiting for ANOTHER destination is delivered first
+static void staging_free_for(kfh_context *c, int slot, const uint8_t *out) {
     for (const PendingCopy &p : c->pending)
         if (p.src == c->h_render[slot] && p.dst != out) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             flush_pending(c);
             break;
         }
-    HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+}
+static uchar4 *render_target(kfh_context *c, int slot, const uint8_t *out) {
+    if (!render_zero_copy(c, slot)) return c->d_render[slot];
+    staging_free_for(c, slot, out);
+    return c->h_render_dev[slot];
+}
+
+static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, uint32_t h) {
+    const size_t bytes = (size_t)w * h * sizeof(uchar4);
+    if (render_is_direct(c)) {
+        for (size_t i = 0; i < c->pending.size();)
+            if (c->pending[i].dst == out) c->pending.erase(c->pending.begin() + i); else ++i;
+        HIP_TRY(hipMemcpyAsync(out, c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+        return;
+    }
+    if (!render_zero_copy(c, slot)) {
+        staging_free_for(c, slot, out);
+        HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     for (PendingCopy &p : c->pending) if (p.dst == out) { p.src = c->h_render[slot]; p.bytes = bytes; return; }
     PendingCopy p = {out, c->h_render[slot], bytes};
     c->pending.push_back(p);
@@ -1039,7 +1070,7 @@ void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { En
     if (!c || !out || w != c->W || h != c->H) return;
     flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_DEPTH);
-    launch::render_depth(c->d_render[0], c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
+    launch::render_depth(render_target(c, 0, out), c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
     prof_end(c, KFH_PROF_RENDER_DEPTH);
     queue_readback(c, 0, out, w, h);
 }
@@ -1048,7 +1079,7 @@ void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { En
     if (!c || !out || w != c->W || h != c->H) return;
     flush_frame(c);
     prof_begin(c, KFH_PROF_RENDER_TRACK);
-    launch::render_track(c->d_render[1], c->d_result, w, h, c->stream);
+    launch::render_track(render_target(c, 1, out), c->d_result, w, h, c->stream);
     prof_end(c, KFH_PROF_RENDER_TRACK);
     queue_readback(c, 1, out, w, h);
 }
@@ -1062,10 +1093,15 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
     fill_control(c, a, k, (unsigned)frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RENDER_BEGIN, a, c->stream);
     const f3 light = mk3(1, 1, -1.0), ambient = mk3((float)0.1, (float)0.1, (float)0.1);   // constant_parameters.h:25-26
+    // the frame's own raycast stands in for the march of the rays it hit, where it is a raycast of this volume with these step sizes
+    // (the view matrices are compared on the device); KFH_RENDER_REUSE=0 marches every ray
+    const char *reuse_env = getenv("KFH_RENDER_REUSE");      // (read per call: the parity test switches it inside one process)
+    const bool reuse = !(reuse_env && reuse_env[0] == '0') && c->ray_maps_fresh && c->ray_maps_largestep == largestep;
     prof_begin(c, KFH_PROF_RENDER_VOLUME);
-    launch::render_volume(c->d_render[2], w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
+    launch::render_volume(render_target(c, 2, out), w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
                           &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient,
-                          c->use_skip ? c->d_skip : nullptr, c->stream);
+                          c->use_skip ? c->d_skip : nullptr,
+                          reuse ? c->d_vertex : nullptr, reuse ? c->d_normal : nullptr, reuse ? &c->d_state->ray : nullptr, c->stream);
     prof_end(c, KFH_PROF_RENDER_VOLUME);
     queue_readback(c, 2, out, w, h);
 }
@@ -1230,6 +1266,7 @@ int64_t kfh_write_buffer(kfh_context *c, const char *name, const void *host_in, 
     if (!c || !name || !host_in || !find_buffer(c, name, &p, &b) || nbytes != b) return KFH_ERR_ARGUMENT;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!HIP_TRY(hipMemcpy(p, host_in, b, hipMemcpyHostToDevice))) return KFH_ERR_HIP;
+    c->ray_maps_fresh = false;      // (whatever was written - the volume, a map, the state - the maps no longer vouch for the volume)
     if (std::string(name) == "volume")   // an injected volume invalidates the brick flags: rebuild them from scratch
         launch::build_skip_grid(c->d_skip, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->stream);
     c->mirror_stale = true;
@@ -1240,6 +1277,7 @@ void *kfh_device_pointer(kfh_context *c, const char *name) { Entry e_(c);
     void *p; size_t b;
     flush_frame(c);
     if (!c || !name || !find_buffer(c, name, &p, &b)) return nullptr;
+    c->ray_maps_fresh = false;      // (the caller may write through the pointer)
     return p;
 }
 
@@ -1450,7 +1488,7 @@ void kfh_k_render_volume(uint8_t *out, uint32_t w, uint32_t h, const int16_t *vo
     if (!d) return;
     launch::render_volume(reinterpret_cast<uchar4 *>(out), w, h, vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), d,
                           near_plane, far_plane, step, largestep, mk3(light[0], light[1], light[2]),
-                          mk3(ambient[0], ambient[1], ambient[2]), nullptr, s);
+                          mk3(ambient[0], ambient[1], ambient[2]), nullptr, nullptr, nullptr, nullptr, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 

@@ -501,34 +501,60 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
     }
 }
 
-// renderVolumeKernel (cpp:880-913)
+// Lambert shading of renderVolumeKernel (cpp:897-907) from a hit position and the NORMALISED surface gradient
+__device__ __forceinline__ uchar4 shade(f3 test, f3 unit_normal, f3 light, f3 ambient) {
+    const f3 diff = normalize3(sub3(light, test));
+    const float dir = fmax_h(dot3(unit_normal, diff), 0.f);
+    const f3 col = scale3(mk3(clamp_h(dir + ambient.x, 0.f, 1.f), clamp_h(dir + ambient.y, 0.f, 1.f),
+                              clamp_h(dir + ambient.z, 0.f, 1.f)), 255);
+    return make_uchar4((unsigned char)col.x, (unsigned char)col.y, (unsigned char)col.z, 0);
+}
+
+// renderVolumeKernel (cpp:880-913).
+// `seen` (or nullptr): the frame's own raycast, to be reused where it applies.  renderVolume marches the rays of `view` from the
+// same near plane with the same two step sizes as raycastKernel and differs in its far plane only (farPlane * 2, cpp:1040): when
+// the view matrix is bit for bit the one the tracking raycast used (the benchmark driver renders from the live pose, kernels.h:179-184)
+// on the same volume, a ray that HIT something there - before the nearer far plane - takes the very same steps here and ends in the
+// same crossing, and raycastKernel has stored what the shading needs: the hit position (vertex map) and normalize(grad) (normal
+// map, x = -2 where the gradient vanishes: black here).  Only the rays that missed are marched again - their march may go on
+// beyond the tracking far plane.  The launcher vouches for the volume and the march parameters, the kernel compares the matrices.
+struct SeenRays { const float4 *vertex, *normal; const RayParams *rp; };
 template <int Q, int FD>
 __global__ __launch_bounds__(RAY_BLOCK) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
                                                        const short2 *__restrict__ vol, unsigned sx, unsigned sy,
                                                        unsigned sz, f3 dim, const RayParams *__restrict__ rp,
                                                        float nearPlane, float farPlane, float step, float largestep,
-                                                       f3 light, f3 ambient, SkipGrid sg, f3 rdim) {
+                                                       f3 light, f3 ambient, SkipGrid sg, f3 rdim, SeenRays seen) {
     unsigned x, y;
     tile_pixel<Q>(x, y, blockIdx.x, blockIdx.y);
     if (x >= W || y >= H) return;
     const M4 view = rp->view;
+    const bool writer = (threadIdx.x & (Q - 1)) == 0;
+    if (seen.rp) {
+        const RayParams T = *seen.rp;
+        bool same = T.enabled != 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) same = same && __builtin_bit_cast(unsigned, T.view.m[r][c]) == __builtin_bit_cast(unsigned, view.m[r][c]);
+        if (same) {      // (uniform over the launch)
+            const float4 v4 = seen.vertex[x + y * W], n4 = seen.normal[x + y * W];
+            if (!(v4.x == 0.f && v4.y == 0.f && v4.z == 0.f)) {      // a hit (uniform over the lanes of a ray: they read the same pixel)
+                if (writer) out[x + y * W] = n4.x == kInvalid ? make_uchar4(0, 0, 0, 0) : shade(mk3(v4.x, v4.y, v4.z), mk3(n4.x, n4.y, n4.z), light, ambient);
+                return;
+            }
+        }
+    }
     VolViewT<FD> v;
     v.data = vol; v.sx = sx; v.sy = sy; v.sz = sz; v.dim = dim; v.rdim = rdim; v.plane = (size_t)sx * sy;
     int work = 0;
     const float4 hit = march<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
-    const bool writer = (threadIdx.x & (Q - 1)) == 0;
     if (Q != 4 && !writer) return;
     uchar4 o = make_uchar4(0, 0, 0, 0);
     if (hit.w > 0) {
         const f3 test = mk3(hit.x, hit.y, hit.z);
         const f3 n = grad_group<Q>(v, test);
-        if (length3(n) > 0) {
-            const f3 diff = normalize3(sub3(light, test));
-            const float dir = fmax_h(dot3(normalize3(n), diff), 0.f);
-            const f3 col = scale3(mk3(clamp_h(dir + ambient.x, 0.f, 1.f), clamp_h(dir + ambient.y, 0.f, 1.f),
-                                      clamp_h(dir + ambient.z, 0.f, 1.f)), 255);
-            o = make_uchar4((unsigned char)col.x, (unsigned char)col.y, (unsigned char)col.z, 0);
-        }
+        if (length3(n) > 0) o = shade(test, normalize3(n), light, ambient);
     }
     if (writer) out[x + y * W] = o;
 }
@@ -639,24 +665,26 @@ unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_tile_dim(ray_gro
 
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
-                   const unsigned char *skip_flags, hipStream_t s) {
+                   const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, hipStream_t s) {
     if (!sizes_addressable(sx, sy, sz, W, H)) { refused("render_volume: volume above 2^30 voxels (or an x-y plane of 2^24): outside the march's 32-bit voxel addressing"); return; }
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
     const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
+    SeenRays seen;
+    seen.vertex = seen_vertex; seen.normal = seen_normal; seen.rp = (seen_vertex && seen_normal) ? seen_rp : nullptr;
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group(W, H)) {
-        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        case 2: k_render_volume<2, 1><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        case 8: k_render_volume<8, 1><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        default: k_render_volume<4, 1><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
         }
     } else {
         switch (ray_group(W, H)) {
-        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
-        default: k_render_volume<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim); launched("k_render_volume"); break;
+        case 1: k_render_volume<1, 0><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        case 2: k_render_volume<2, 0><<<ray_grid(2, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        case 8: k_render_volume<8, 0><<<ray_grid(8, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
+        default: k_render_volume<4, 0><<<ray_grid(4, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
         }
     }
 }

@@ -224,3 +224,70 @@ def test_880_free_running_frames_against_the_fixed_schedule_floors(hip, kfmod, o
     print("\n880 frames: max |position - oracle| = %.3g m; voxels off by > 1e-4: HIP %.3g; fixed-schedule CPP-vs-OpenMP floors %s"
           % (worst[0], hip_frac, ", ".join("T=%d %.3g" % kv for kv in sorted(floors.items()))))
     assert hip_frac <= max(floors.values()), (hip_frac, floors)
+
+
+def test_render_volume_from_the_frames_raycast_equals_the_march(hip, kfmod, orc, monkeypatch):
+    """renderVolume (cpp:880-913, 1032-1046) shades the rays the frame's own raycast hit from its vertex / normal maps when the view
+    matrix is bit for bit the tracking one, and marches only the rays that missed.  Against the oracle's march and
+    against the same library with the reuse switched off, byte for byte: from the live pose (reuse), from a view pose of the
+    caller's (no reuse: the matrices differ), after an integration without a raycast (the maps no longer vouch for the volume),
+    with another large step (other march), and in a scene whose far wall lies between the tracking far plane (4 m) and the
+    rendering one (8 m) - rays that miss in the tracking raycast and hit here."""
+    n = 7
+    s = synth.make_stream(n, W, H)
+    k = list(s.k)
+    res = (256, 256, 256)
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+
+    def both(frame, rate, largestep):
+        monkeypatch.setenv("KFH_RENDER_REUSE", "0")
+        marched = g.render_volume(frame, rate, k, largestep)
+        monkeypatch.delenv("KFH_RENDER_REUSE")
+        reused = g.render_volume(frame, rate, k, largestep)
+        assert np.array_equal(marched, reused), frame
+        return reused
+
+    for f in range(n):
+        g.set_pose(o.get_pose())
+        g.preprocessing(s.depth_mm[f]); o.preprocessing(s.depth_mm[f])
+        g.tracking(k, util.ICP_THRESHOLD, 1, f); o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        g.set_pose(o.get_pose())
+        g.integration(k, 1, util.MU, f); o.integration(k, 1, util.MU, f)
+        g.raycasting(k, util.MU, f); o.raycasting(k, util.MU, f)
+        img = both(f, 1, 0.75 * util.MU)
+        assert np.array_equal(img, o.render_volume(f, 1, k, 0.75 * util.MU)), f
+    assert img[..., :3].max() > 0
+    # another large step than the tracking raycast's: every ray is marched, and rightly so
+    assert np.array_equal(both(n - 1, 1, 0.5 * util.MU), o.render_volume(n - 1, 1, k, 0.5 * util.MU))
+    # a view pose of the caller's (kernels.h:179-184): other matrices
+    view = o.get_pose().copy()
+    view[0, 3] += 0.05
+    g.set_view_pose(view)
+    img_view = both(n - 1, 1, 0.75 * util.MU)
+    g.set_view_pose(None)
+    assert not np.array_equal(img_view, img)
+    # an integration after the raycast: the maps describe the volume as it was
+    g.preprocessing(s.depth_mm[n - 1]); o.preprocessing(s.depth_mm[n - 1])
+    g.integration(k, 1, util.MU, n - 1); o.integration(k, 1, util.MU, n - 1)
+    assert np.array_equal(both(n - 1, 1, 0.75 * util.MU), o.render_volume(n - 1, 1, k, 0.75 * util.MU))
+    g.close(); o.close()
+    # far wall between 4 m and 8 m: a 9.6 m volume, a plane 6 m in front of the camera
+    dim = (9.6, 9.6, 9.6)
+    depth = np.full((H, W), 6000, np.uint16)
+    depth[:, : W // 2] = 2500                                   # the left half is a nearer wall: hit by both raycasts
+    pos = np.array([4.8, 4.8, 0.3], np.float32)
+    g = kfmod.Kfusion((W, H), (192, 192, 192), dim, pos)
+    o = orc.OracleKfusion((W, H), (192, 192, 192), dim, pos, omp=True)
+    for f in range(5):
+        for x in (g, o):
+            x.preprocessing(depth); x.tracking(k, util.ICP_THRESHOLD, 1, f)
+        g.set_pose(o.get_pose())
+        for x in (g, o):
+            x.integration(k, 1, util.MU, f); x.raycasting(k, util.MU, f)
+    img = both(4, 1, 0.75 * util.MU)
+    assert np.array_equal(img, o.render_volume(4, 1, k, 0.75 * util.MU))
+    vz = g.buffer("vertex")[..., 2]
+    assert (vz[:, W // 2 + 8:] == 0).mean() > 0.9 and (vz[:, : W // 2 - 8] > 0).mean() > 0.9      # the far half misses in the tracking raycast ...
+    assert (img[:, W // 2 + 8:, :3].max(axis=-1) > 0).mean() > 0.9                                 # ... and is there in the rendering
+    g.close(); o.close()
