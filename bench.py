@@ -227,6 +227,8 @@ def timed_run(S, make_leg, multi, n_warm, n_steps, prof_every):
         leg.sync()
         if prof_every > 0 and not leg.with_renders:
             leg.kf.set_profiling(["icp", "integrate", "raycast"], every=prof_every, rotate=True)
+        elif prof_every < 0 and leg.with_renders and leg.kf is not None:      # the render-profile leg: an event pair around every render launch
+            leg.kf.set_profiling(["render_depth", "render_track", "render_volume"], every=1)
     except Exception as e:       # noqa: BLE001
         err = e
     if not multi.all_ok(err is None, S.dist, S.coll_device):
@@ -268,6 +270,7 @@ def cpu_baseline(wl, cfg, budget_s, max_frames, min_frames=8):
     orc.build()
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    orc.set_omp_threads(cores)      # (the environment variable is read once, when libgomp is first loaded - torch has loaded it long before this point)
     W, H, vres, pyramid, irate, _ = cfg
     k = list(wl.k)
     o = orc.OracleKfusion((W, H), (vres,) * 3, (wl.volume_size,) * 3, wl.init_pos, pyramid, omp=True)
@@ -610,6 +613,15 @@ def measure(S, args, multi, config_name, steps, warmup, full):
     fps_total = fps_total_error = None
     if full and not args.no_total:      # the same loop plus the three renders and their read-back
         fps_total, fps_total_error = secondary(lambda: mk(True), "render")
+    render_prof = None
+    if full and not args.no_total:      # a short leg of its own with an event pair around every render kernel (it would cost the leg above ~5 %)
+        _, rleg, rerr = timed_run(S, lambda: mk(True), multi, min(warmup, 8), min(40, steps), -1)
+        if rleg is not None:
+            if rerr is None and not S.dry:
+                render_prof = rleg.kf.read_profile()
+            rleg.close()
+        if rerr is not None:
+            print("bench.py: rank %d: the render-profile leg of %s failed: %r" % (S.rank, config_name, rerr), file=sys.stderr)
     fps_host_input = fps_host_input_error = None
     if not (full and args.no_total):    # the queued loop fed from pageable host memory (PCIe inside the loop; never `value`)
         fps_host_input, fps_host_input_error = secondary(lambda: mk(False, host_input=True), "host-input")
@@ -668,6 +680,29 @@ def measure(S, args, multi, config_name, steps, warmup, full):
         host = host_buffers_leg(wl, cfg, n_frames)
     roof = rooflines(cfg, config_name, prof, prof_every, updated, integrated, icp_by_level, n_frames, v_distinct,
                      measure=S.world == 1 and not args.no_measure_traffic, icp_launch_count=icp_launch_count)
+    if render_prof:
+        # renderDepth 8 P (float depth in, uchar4 out), renderTrack 8 P (the int32 result map in, uchar4 out), renderVolume
+        # 4 P + 4 V' (V' = distinct voxels its march samples: taken as the tracking raycast's V - the same rays, a farther far plane).
+        # Their read-back is the expensive part of a rendered frame: 4 P bytes per image over PCIe, in the compute stream.
+        P = W * H
+        alg = {"render_depth": 8.0 * P, "render_track": 8.0 * P, "render_volume": 4.0 * P + 4.0 * (v_distinct or 0.0)}
+        for name, bytes_ in alg.items():
+            ms, n = render_prof[name]
+            if n:
+                gbs = bytes_ / (ms / n * 1e-3) / 1e9
+                roof[name] = {"kernel": "k_" + name, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "avg_us": round(ms / n * 1e3, 2), "launches": n,
+                              "algorithmic_bytes_per_launch": round(bytes_)}
+        if fps_total:
+            launched = {k: render_prof[k][1] for k in alg}
+            frames_r = max(1, launched["render_depth"])
+            kern_us = sum(render_prof[k][0] for k in alg) / frames_r * 1e3
+            images = sum(launched.values()) / frames_r
+            roof["render_readback"] = {"what": "device-to-host copies of the rendered images in the compute stream (hipMemcpyAsync into pinned staging)",
+                                       "bytes_per_frame": round(images * 4.0 * P), "images_per_frame": round(images, 2),
+                                       "render_kernels_us_per_frame": round(kern_us, 2),
+                                       "frame_us_with_renders": round(1e6 / fps_total, 2), "frame_us_without": round(t_max / (steps * spg) * 1e6, 2),
+                                       "readback_and_queue_breaks_us_per_frame": round(1e6 / fps_total - t_max / (steps * spg) * 1e6 - kern_us, 2)}
     res = {
         "workload": workload_string(config_name, cfg, wl),
         "value": round(total_frames / t_max, 2), "ms_per_step": round(t_max / (steps * spg) * 1e3, 4), "steps": steps, "warmup": warmup,
@@ -729,7 +764,8 @@ def run(S, args, multi):
         print(json.dumps(out))
         return
     roof, prof, irate = head["roof"], head["prof"], head["irate"]
-    dominant = max(roof, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if roof else None
+    frame_kernels = [k for k in ("icp", "integrate", "raycast") if k in roof]      # (the render entries are never the headline's roofline)
+    dominant = max(frame_kernels, key=lambda k: prof[k][0] / max(prof[k][1], 1) * (1.0 if k != "integrate" else 1.0 / max(1, irate))) if frame_kernels else None
     out = {
         "metric": "frames/sec, KinectFusion computation (preprocess+track+integrate+raycast), %s, queued frames, "
                   "living-room stream %%dx%%d -c 1 @%%d^3" % ("PAGEABLE HOST INPUT (--host-input)" if args.host_input else "device-resident input") % (W, H, vres),

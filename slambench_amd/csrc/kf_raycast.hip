@@ -7,6 +7,12 @@ namespace kf {
 // =====================================================================================
 // Volume sampling (commons.h:191-301) and the ray march (cpp:674-725)
 // =====================================================================================
+// Stage probes for the instruction census (profiles/r05_raycast_census.txt): only in a build with -DKFH_RAY_PROBES=1; results are wrong
+// with a probe on and the shipped library has no such path.
+#ifndef KFH_RAY_PROBES
+#define KFH_RAY_PROBES 0
+#endif
+
 template <int FD>
 struct VolViewT {
     static constexpr int kFastDiv = FD;
@@ -191,6 +197,7 @@ struct SkipGrid {
     float kx, ky, kz;             // size / dim per axis, divided by 8 (voxels -> bricks)
     float bx_max, by_max, bz_max; // last brick index per axis, as floats
     int two_phase;                // loop shape (only with flags)
+    int probe;                    // census build only (-DKFH_RAY_PROBES=1, results wrong): 1 = every ray ends after its set-up, 2 = no surface gradient, 4 = every sample in an empty brick
     unsigned long long *trace;    // debugging (KFH_RAY_TRACE): per wave {start, end} of the 100 MHz wall clock, else nullptr
     const unsigned *order;        // launch slot -> screen tile (most expensive tiles of the last frame first), or nullptr
     unsigned tiles_x, tiles_y;    // the tile grid of the dispatch order: tiles of 2x2 wave tiles, whatever the workgroup size
@@ -215,6 +222,24 @@ __device__ __forceinline__ unsigned char brick_flag(const SkipGrid &g, const V &
 }
 template <class V>
 __device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const V &v, f3 pos) { return brick_flag(g, v, pos) == 0; }
+
+// The same look-up for the sample at parameter t of a ray, without forming the sample's position: the brick coordinate
+// (origin + dir t) k - 1/16 as ONE multiply-add per axis of two per-ray constants.  It differs from the look-up on the rounded position
+// by a few 2^-24 of a brick - far inside the one-voxel slack the flags' dilation allows for - and in a round that finds only empty
+// bricks the position is never needed (6 of a round's ~45 vector instructions).
+struct BrickRay { f3 o, d; };
+__device__ __forceinline__ BrickRay brick_ray(const SkipGrid &g, f3 origin, f3 dir) {
+    BrickRay r;
+    r.o = mk3(__builtin_fmaf(origin.x, g.kx, -0.0625f), __builtin_fmaf(origin.y, g.ky, -0.0625f), __builtin_fmaf(origin.z, g.kz, -0.0625f));
+    r.d = mk3(dir.x * g.kx, dir.y * g.ky, dir.z * g.kz);
+    return r;
+}
+__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const BrickRay &r, float t) {
+    const unsigned bx = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.x, t, r.o.x), 0.f, g.bx_max);
+    const unsigned by = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.y, t, r.o.y), 0.f, g.by_max);
+    const unsigned bz = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.z, t, r.o.z), 0.f, g.bz_max);
+    return g.flags[__umul24(__umul24(bz, (unsigned)g.nby) + by, (unsigned)g.nbx) + bx] == 0;
+}
 
 // full rebuild (after reset or when a volume is injected from the host)
 __global__ __launch_bounds__(256) void k_build_skip_grid(unsigned char *__restrict__ flags, const short2 *__restrict__ vol,
@@ -246,7 +271,8 @@ __device__ __forceinline__ float4 cast_ray(const V &v, const SkipGrid &sg, unsig
         float t = tnear, stepsize = largestep;
         const f3 p0 = add3(origin, scale3(dir, t));
         // `lazy`: the last accepted sample (f_t) lies in an empty brick; it is known to be >= 0.81 but not evaluated
-        bool lazy = sg.flags && brick_is_empty(sg, v, p0);
+        const BrickRay br = sg.flags ? brick_ray(sg, origin, dir) : BrickRay{};
+        bool lazy = sg.flags && brick_is_empty(sg, br, t);
         float t_ft = t;
         float f_t = lazy ? 1.0f : interp(v, p0);
         float f_tt = 0;
@@ -256,7 +282,7 @@ __device__ __forceinline__ float4 cast_ray(const V &v, const SkipGrid &sg, unsig
                 // a wave first run through their free-space samples in a short loop and then take the expensive
                 // sample together.
                 while (true) {
-                    while (t < tfar && brick_is_empty(sg, v, add3(origin, scale3(dir, t)))) {
+                    while (t < tfar && brick_is_empty(sg, br, t)) {
                         lazy = true;
                         t_ft = t;
                         t += stepsize;
@@ -272,9 +298,8 @@ __device__ __forceinline__ float4 cast_ray(const V &v, const SkipGrid &sg, unsig
             } else {
                 for (; t < tfar; t += stepsize) {
                     ++work;
-                    const f3 p = add3(origin, scale3(dir, t));
-                    if (sg.flags && brick_is_empty(sg, v, p)) { lazy = true; t_ft = t; continue; }
-                    f_tt = interp(v, p);
+                    if (sg.flags && brick_is_empty(sg, br, t)) { lazy = true; t_ft = t; continue; }
+                    f_tt = interp(v, add3(origin, scale3(dir, t)));
                     if (f_tt < 0) break;
                     if (f_tt < 0.8f) stepsize = step;
                     f_t = f_tt;
@@ -334,6 +359,10 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
     const float tfar = fmin_h(smallest_tmax, farPlane);
     const float4 miss = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!(tnear < tfar)) return miss;
+#if KFH_RAY_PROBES
+    if (sg.probe & 1) return make_float4(dir.x, dir.y, dir.z, 0.f);
+#endif
+    const BrickRay br = sg.flags ? brick_ray(sg, origin, dir) : BrickRay{};
     float t = tnear, stepsize = largestep;
     bool small = false;          // stepsize has been switched to `step`
     bool lazy = false;           // f_t lies in an empty brick: >= 0.81, value not evaluated
@@ -348,9 +377,12 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
         bool s_lazy = false;
         float f = 0.f;
         if (in_range) {
-            const f3 p = add3(origin, scale3(dir, tq));
-            if (sg.flags && brick_is_empty(sg, v, p)) s_lazy = true;
-            else f = interp(v, p);
+#if KFH_RAY_PROBES
+            if (sg.flags && (brick_is_empty(sg, br, tq) || (sg.probe & 4))) s_lazy = true;
+#else
+            if (sg.flags && brick_is_empty(sg, br, tq)) s_lazy = true;
+#endif
+            else f = interp(v, add3(origin, scale3(dir, tq)));
         }
         // what the serial loop does at this sample: 0 continue, 1 out of range, 2 zero crossing, 3 large->small step
         int kind = 0;
@@ -486,7 +518,11 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_raycast(float4 *__restrict__ vert
     if (Q != 4 && !writer) return;
     const unsigned p = x + y * W;
     if (hit.w > 0.0) {                                  // uniform over the lanes of a ray
+#if KFH_RAY_PROBES
+        const f3 n = (sg.probe & 2) ? mk3(hit.x, hit.y, hit.z) : grad_group<Q>(v, mk3(hit.x, hit.y, hit.z));
+#else
         const f3 n = grad_group<Q>(v, mk3(hit.x, hit.y, hit.z));
+#endif
         if (!writer) return;
         vertex[p] = make_float4(hit.x, hit.y, hit.z, 0.f);
         if (length3(n) == 0) {
@@ -569,6 +605,12 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     g.bx_max = (float)((sx - 1) >> 3); g.by_max = (float)((sy - 1) >> 3); g.bz_max = (float)((sz - 1) >> 3);
     static const long tp = env_long("KFH_RAY_TWO_PHASE", 0, 1, 0);
     g.two_phase = (flags && tp) ? 1 : 0;
+#if KFH_RAY_PROBES
+    static const long probe_env = env_long("KFH_RAY_PROBE_STAGE", 0, 7, 0);
+    g.probe = (int)probe_env;
+#else
+    g.probe = 0;
+#endif
     g.trace = nullptr;
     g.order = nullptr; g.cost = nullptr;
     g.tiles_x = 0; g.tiles_y = 0;

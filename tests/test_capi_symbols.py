@@ -62,7 +62,7 @@ def test_default_build_has_no_result_changing_switches():
     if not os.path.exists(_capi.LIB_PATH):
         build.build_library()
     blob = open(_capi.LIB_PATH, "rb").read()
-    for name in (b"KFH_INTEGRATE_DBG", b"KFH_INT_PROBE_STAGE", b"KFH_INT_PROBE_FROM", b"KFH_TAIL_PROBE", b"KFH_INT_SPECULATE"):
+    for name in (b"KFH_INTEGRATE_DBG", b"KFH_INT_PROBE_STAGE", b"KFH_INT_PROBE_FROM", b"KFH_TAIL_PROBE", b"KFH_INT_SPECULATE", b"KFH_RAY_PROBE_STAGE"):
         assert name not in blob, "the default build of libkfusion_hip.so reads %s" % name.decode()
     assert b"KFH_ICP_TAIL_TIMEOUT_TICKS" in blob and b"KFH_ENABLE_TEST_HOOKS" in blob
     src = open(os.path.join(ROOT, "slambench_amd", "csrc", "kf_icp.hip")).read()
