@@ -532,14 +532,19 @@ __device__ __forceinline__ void ray_order_block(RayOrderShared &sh, unsigned *__
 }
 
 // ---- brick flags of the exact empty-space skipping (set by k_integrate, read by the ray march: kf_raycast.hip) -----------------
+#ifndef KFH_BRICK_SHIFT
+#define KFH_BRICK_SHIFT 3      // bricks of 8^3 voxels (2 = 4^3: measured in profiles/r05_sweeps.md)
+#endif
+constexpr int BRICK_SHIFT = KFH_BRICK_SHIFT, BRICK = 1 << BRICK_SHIFT;
+__host__ __device__ inline unsigned bricks_along(unsigned voxels) { return (voxels + BRICK - 1) >> BRICK_SHIFT; }
 constexpr short kSkipShortFwd = 26600;
 constexpr short kSkipShort = kSkipShortFwd;
 __device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ void mark_bricks(unsigned char *flags, int nbx, int nby, int nbz, int x, int y, int z) {
-    const int x0 = x >= 2 ? (x - 2) >> 3 : 0, x1 = imin((x + 1) >> 3, nbx - 1);
-    const int y0 = y >= 2 ? (y - 2) >> 3 : 0, y1 = imin((y + 1) >> 3, nby - 1);
-    const int z0 = z >= 2 ? (z - 2) >> 3 : 0, z1 = imin((z + 1) >> 3, nbz - 1);
+    const int x0 = x >= 2 ? (x - 2) >> BRICK_SHIFT : 0, x1 = imin((x + 1) >> BRICK_SHIFT, nbx - 1);
+    const int y0 = y >= 2 ? (y - 2) >> BRICK_SHIFT : 0, y1 = imin((y + 1) >> BRICK_SHIFT, nby - 1);
+    const int z0 = z >= 2 ? (z - 2) >> BRICK_SHIFT : 0, z1 = imin((z + 1) >> BRICK_SHIFT, nbz - 1);
     for (int bz = z0; bz <= z1; ++bz)
         for (int by = y0; by <= y1; ++by)
             for (int bx = x0; bx <= x1; ++bx) flags[bx + nbx * (by + nby * bz)] = 1;

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                     // (pixel 0 for the others: a load nobody looks at; 24-bit multiply: the launcher refuses images of 2^26 pixels and more)
                     pix[i] = inside ? __umul24((unsigned)py, W * 4u) + ((unsigned)px << 2) : 0u;
                     march_step<KZ>(T, da, db, dc);
+                } else {
+                    pix[i] = 0u;      // (a voxel beyond the chunk's end: its depth gather below is unconditional and must have an address)
                 }
             }
             ++work;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
                 const short ts = (short)(tsdf * 32766.0f);
                 store_voxel(vol, voff + (unsigned)i * plane4, (unsigned)(unsigned short)ts | ((unsigned)(unsigned short)(short)w << 16));
                 if (skip_flags && ts < kSkipShortFwd && cx16 >= kSkipShortFwd)   // flags are sticky: first crossing only
-                    mark_bricks(skip_flags, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3, x, y, zb + i);
+                    mark_bricks(skip_flags, bricks_along(sx), bricks_along(sy), bricks_along(sz), x, y, zb + i);
                 ++updated;
             }
         }

@@ -214,9 +214,9 @@ __device__ __forceinline__ unsigned char brick_flag(const SkipGrid &g, const V &
     // brick of the base voxel: floor((pos * size/dim - 0.5) / 8), clamped to the grid - as three instructions per axis
     // (fused multiply-add, median-of-three clamp in float, truncation: the clamped value is >= 0).  The base voxel is
     // only located to within one voxel here, which is what the dilation of the flags allows for.
-    const unsigned bx = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.x, g.kx, -0.0625f), 0.f, g.bx_max);
-    const unsigned by = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.y, g.ky, -0.0625f), 0.f, g.by_max);
-    const unsigned bz = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.z, g.kz, -0.0625f), 0.f, g.bz_max);
+    const unsigned bx = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.x, g.kx, -0.5f / BRICK), 0.f, g.bx_max);
+    const unsigned by = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.y, g.ky, -0.5f / BRICK), 0.f, g.by_max);
+    const unsigned bz = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pos.z, g.kz, -0.5f / BRICK), 0.f, g.bz_max);
     (void)v;
     return g.flags[__umul24(__umul24(bz, (unsigned)g.nby) + by, (unsigned)g.nbx) + bx];
 }
@@ -230,7 +230,7 @@ __device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const V &v, f3
 struct BrickRay { f3 o, d; };
 __device__ __forceinline__ BrickRay brick_ray(const SkipGrid &g, f3 origin, f3 dir) {
     BrickRay r;
-    r.o = mk3(__builtin_fmaf(origin.x, g.kx, -0.0625f), __builtin_fmaf(origin.y, g.ky, -0.0625f), __builtin_fmaf(origin.z, g.kz, -0.0625f));
+    r.o = mk3(__builtin_fmaf(origin.x, g.kx, -0.5f / BRICK), __builtin_fmaf(origin.y, g.ky, -0.5f / BRICK), __builtin_fmaf(origin.z, g.kz, -0.5f / BRICK));
     r.d = mk3(dir.x * g.kx, dir.y * g.ky, dir.z * g.kz);
     return r;
 }
@@ -629,9 +629,9 @@ namespace launch {
 static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned sy, unsigned sz, f3 dim) {
     SkipGrid g;
     g.flags = flags;
-    g.nbx = (sx + 7) >> 3; g.nby = (sy + 7) >> 3; g.nbz = (sz + 7) >> 3;
-    g.kx = sx / dim.x * 0.125f; g.ky = sy / dim.y * 0.125f; g.kz = sz / dim.z * 0.125f;
-    g.bx_max = (float)((sx - 1) >> 3); g.by_max = (float)((sy - 1) >> 3); g.bz_max = (float)((sz - 1) >> 3);
+    g.nbx = bricks_along(sx); g.nby = bricks_along(sy); g.nbz = bricks_along(sz);
+    g.kx = sx / dim.x * (1.0f / BRICK); g.ky = sy / dim.y * (1.0f / BRICK); g.kz = sz / dim.z * (1.0f / BRICK);
+    g.bx_max = (float)((sx - 1) >> BRICK_SHIFT); g.by_max = (float)((sy - 1) >> BRICK_SHIFT); g.bz_max = (float)((sz - 1) >> BRICK_SHIFT);
     static const long tp = env_long("KFH_RAY_TWO_PHASE", 0, 1, 0);
     g.two_phase = (flags && tp) ? 1 : 0;
 #if KFH_RAY_PROBES
@@ -648,11 +648,11 @@ static SkipGrid make_skip_grid(const unsigned char *flags, unsigned sx, unsigned
     return g;
 }
 
-size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz) { return (size_t)((sx + 7) >> 3) * ((sy + 7) >> 3) * ((sz + 7) >> 3); }
+size_t skip_grid_bytes(unsigned sx, unsigned sy, unsigned sz) { return (size_t)bricks_along(sx) * bricks_along(sy) * bricks_along(sz); }
 
 void build_skip_grid(unsigned char *flags, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, hipStream_t s) {
     hipMemsetAsync(flags, 0, skip_grid_bytes(sx, sy, sz), s);
-    k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, (sx + 7) >> 3, (sy + 7) >> 3, (sz + 7) >> 3); launched("k_build_skip_grid");
+    k_build_skip_grid<<<2048, 256, 0, s>>>(flags, reinterpret_cast<const short2 *>(vol), sx, sy, sz, bricks_along(sx), bricks_along(sy), bricks_along(sz)); launched("k_build_skip_grid");
 }
 
 // all three axes verified and every numerator pos * size below 2^24
