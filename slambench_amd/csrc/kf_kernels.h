@@ -201,7 +201,8 @@ void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
-                   const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, hipStream_t s);
+                   const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, float seen_far_plane,
+                   hipStream_t s);
 // (seen_*: the vertex / normal maps and the parameters of a raycast of the SAME volume with the same near plane and step sizes, or
 // nullptr: rays that hit there are shaded from the maps where the view matrices agree bit for bit, kf_raycast.hip k_render_volume)
 }  // namespace launch

@@ -1101,7 +1101,7 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
     launch::render_volume(render_target(c, 2, out), w, h, c->d_volume, c->volRes[0], c->volRes[1], c->volRes[2], c->volDim,
                           &c->d_state->render, nearPlane, farPlane * 2.0f, c->step, largestep, light, ambient,
                           c->use_skip ? c->d_skip : nullptr,
-                          reuse ? c->d_vertex : nullptr, reuse ? c->d_normal : nullptr, reuse ? &c->d_state->ray : nullptr, c->stream);
+                          reuse ? c->d_vertex : nullptr, reuse ? c->d_normal : nullptr, reuse ? &c->d_state->ray : nullptr, farPlane, c->stream);
     prof_end(c, KFH_PROF_RENDER_VOLUME);
     queue_readback(c, 2, out, w, h);
 }
@@ -1488,7 +1488,7 @@ void kfh_k_render_volume(uint8_t *out, uint32_t w, uint32_t h, const int16_t *vo
     if (!d) return;
     launch::render_volume(reinterpret_cast<uchar4 *>(out), w, h, vol, size[0], size[1], size[2], mk3(dim[0], dim[1], dim[2]), d,
                           near_plane, far_plane, step, largestep, mk3(light[0], light[1], light[2]),
-                          mk3(ambient[0], ambient[1], ambient[2]), nullptr, nullptr, nullptr, nullptr, s);
+                          mk3(ambient[0], ambient[1], ambient[2]), nullptr, nullptr, nullptr, nullptr, 0.f, s);
     HIP_TRY(hipStreamSynchronize(s));
 }
 

@@ -583,7 +583,18 @@ __device__ __forceinline__ uchar4 shade(f3 test, f3 unit_normal, f3 light, f3 am
 // same crossing, and raycastKernel has stored what the shading needs: the hit position (vertex map) and normalize(grad) (normal
 // map, x = -2 where the gradient vanishes: black here).  Only the rays that missed are marched again - their march may go on
 // beyond the tracking far plane.  The launcher vouches for the volume and the march parameters, the kernel compares the matrices.
-struct SeenRays { const float4 *vertex, *normal; const RayParams *rp; };
+struct SeenRays { const float4 *vertex, *normal; const RayParams *rp; float far_plane; };      // far_plane: the tracking raycast's
+
+// where the ray of pixel (px, py) leaves the volume: smallest_tmax of the slab test, with the expressions of cast_ray (cpp:685-699)
+__device__ __forceinline__ float ray_volume_exit(const M4 &view, unsigned px, unsigned py, f3 dim) {
+    const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
+    const f3 dir = rotate(view, mk3((float)px, (float)py, 1.f));
+    const f3 invR = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const f3 tbot = mul3(scale3(invR, -1.0f), origin);
+    const f3 ttop = mul3(invR, sub3(dim, origin));
+    const f3 tmax = mk3(fmax_h(ttop.x, tbot.x), fmax_h(ttop.y, tbot.y), fmax_h(ttop.z, tbot.z));
+    return fmin_h(fmin_h(tmax.x, tmax.y), fmin_h(tmax.x, tmax.z));
+}
 template <int Q, int FD>
 __global__ __launch_bounds__(RAY_BLOCK) void k_render_volume(uchar4 *__restrict__ out, unsigned W, unsigned H,
                                                        const short2 *__restrict__ vol, unsigned sx, unsigned sy,
@@ -606,6 +617,13 @@ __global__ __launch_bounds__(RAY_BLOCK) void k_render_volume(uchar4 *__restrict_
             const float4 v4 = seen.vertex[x + y * W], n4 = seen.normal[x + y * W];
             if (!(v4.x == 0.f && v4.y == 0.f && v4.z == 0.f)) {      // a hit (uniform over the lanes of a ray: they read the same pixel)
                 if (writer) out[x + y * W] = n4.x == kInvalid ? make_uchar4(0, 0, 0, 0) : shade(mk3(v4.x, v4.y, v4.z), mk3(n4.x, n4.y, n4.z), light, ambient);
+                return;
+            }
+            // A ray that missed there and leaves the volume before the TRACKING far plane has the same far end here
+            // (min(exit, far) = exit under both far planes): the same march, the same miss - black, without marching.  Only a ray
+            // that the tracking far plane cut short is marched (a NaN exit compares false and is marched).
+            if (ray_volume_exit(view, x, y, dim) <= seen.far_plane) {
+                if (writer) out[x + y * W] = make_uchar4(0, 0, 0, 0);
                 return;
             }
         }
@@ -736,13 +754,14 @@ unsigned ray_tiles(unsigned W, unsigned H) { const dim3 g = ray_tile_dim(ray_gro
 
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
-                   const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, hipStream_t s) {
+                   const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, float seen_far_plane,
+                   hipStream_t s) {
     if (!sizes_addressable(sx, sy, sz, W, H)) { refused("render_volume: volume above 2^30 voxels (or an x-y plane of 2^24): outside the march's 32-bit voxel addressing"); return; }
     const short2 *vv = reinterpret_cast<const short2 *>(vol);
     const SkipGrid sg = make_skip_grid(skip_flags, sx, sy, sz, dim);
     const f3 rdim = mk3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     SeenRays seen;
-    seen.vertex = seen_vertex; seen.normal = seen_normal; seen.rp = (seen_vertex && seen_normal) ? seen_rp : nullptr;
+    seen.vertex = seen_vertex; seen.normal = seen_normal; seen.rp = (seen_vertex && seen_normal) ? seen_rp : nullptr; seen.far_plane = seen_far_plane;
     if (fast_division(dim, sx, sy, sz, s)) {
         switch (ray_group(W, H)) {
         case 1: k_render_volume<1, 1><<<ray_grid(1, W, H), RAY_BLOCK, 0, s>>>(out, W, H, vv, sx, sy, sz, dim, p, nearPlane, farPlane, step, largestep, light, ambient, sg, rdim, seen); launched("k_render_volume"); break;
