@@ -1021,9 +1021,9 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
 // Where a render kernel writes, and how the image reaches the caller's buffer:
 //  * phase API (the benchmark driver, which synchronises right after the renders): device buffer, then one copy straight into the
 //    caller's (pageable) buffer - the runtime returns once it is there (rendering column of the driver 205 -> 122 us per frame);
-//  * queued frames (kfh_compute_frame): device buffer, an asynchronous copy into pinned staging in the compute stream, and the host
-//    moves the image into the caller's buffer at the next synchronisation - the queue is not stalled.  (Round 5 measured the render
-//    kernels writing the image into the pinned buffer themselves, KFH_RENDER_ZEROCOPY=1: 4-byte stores over PCIe, 2.7 MB per frame at
+//  * queued frames (kfh_compute_frame): device buffer, then a copy KERNEL of the compute stream into pinned staging (queue_readback),
+//    and the host moves the image into the caller's buffer at the next synchronisation - the queue is not stalled.  (Round 5 also
+//    measured the render kernels writing the image into the pinned buffer themselves, KFH_RENDER_ZEROCOPY=1: 4-byte stores over PCIe,
 //    ~16 GB/s - fps_total 2780 against 3430 with the copy engine, profiles/r05_sweeps.md; the switch stays for the record, off.)
 //    KFH_RENDER_DIRECT=0/1 forces staged / direct.
 static bool render_is_direct(const kfh_context *c) {
@@ -1059,7 +1059,14 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
     }
     if (!render_zero_copy(c, slot)) {
         staging_free_for(c, slot, out);
-        HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
+        // The copy is a KERNEL of the compute stream that stores 16 bytes per lane into the pinned buffer (256 blocks: one per CU):
+        // ~45 GB/s over PCIe and no copy-engine hand-over, against ~27 GB/s for hipMemcpyAsync at this size - fps_total 3485 -> 4050
+        // at cfg2 (profiles/r05_copy_kernel.txt).  KFH_RENDER_COPY_KERNEL=<blocks> sets the grid, 0 = the copy engine.
+        static const long copy_blocks = [] { const char *e = getenv("KFH_RENDER_COPY_KERNEL"); const long v = e ? atol(e) : 256L; return (v >= 0 && v <= 65535) ? v : 256L; }();
+        if (copy_blocks > 0 && c->h_render_dev[slot] && bytes % 16 == 0)
+            launch::copy_out(c->h_render_dev[slot], c->d_render[slot], bytes, (unsigned)copy_blocks, c->stream);
+        else
+            HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
     }
     for (PendingCopy &p : c->pending) if (p.dst == out) { p.src = c->h_render[slot]; p.bytes = bytes; return; }
     PendingCopy p = {out, c->h_render[slot], bytes};
