@@ -11,17 +11,22 @@ namespace kf {
 // the z0 additions in registers so that its float state carries the bits of the serial march.
 // The six running sums are kept as three float pairs and advanced with packed adds (v_pk_add_f32).
 //
-// Most voxels do not project into the image, and the kernel is instruction bound, not byte bound, so the work per
-// rejected voxel is what matters.  The z march is cut into batches of IB voxels:
-//   * batch reject: x/z and y/z are monotonic along the column while z stays positive, so if BOTH end voxels of a batch
-//     are outside the image on the same side with a 0.1-pixel margin (tested with multiplications), or both are behind
-//     the camera, every voxel of the batch fails cpp:647-653 and only the IB packed additions are spent on it;
-//   * otherwise each voxel runs the reference tests, with the two IEEE divisions of the projection skipped for voxels
-//     that the same multiplication test already puts outside;
-//   * the depth gathers of a batch are issued together, then the voxel reads of the survivors;
+// Most voxels do not project into the image, and the kernel is bound by instruction issue, not by bytes (census and per-wave traces in
+// profiles/r05_sweeps.md), so the work per rejected voxel - vector AND scalar instructions - is what matters.  The z march is cut
+// into chunks (one wave per 16 x 4 patch and chunk) and the chunks into batches of IB voxels:
+//   * chunk reject: the un-marched end voxels of the whole chunk against the image, with the launch's rounding bound to spare; a
+//     thread whose chunk is out replays nothing and sits the batch loop out;
+//   * batch reject: x/z and y/z are monotonic along the column while z stays positive, so if the batch's first voxel and the NEXT
+//     batch's first voxel are outside the image on the same side with a quarter-pixel margin (four signed side distances per end
+//     point, each end point evaluated once), or both are behind the camera, every voxel of the batch fails cpp:647-653 and only the
+//     IB packed additions are spent on it;
+//   * otherwise the detailed pass, straight-line code with selects: rcp-based projection, ONE near-integer test for both coordinates
+//     that sends the wave to the two IEEE divisions, unconditional depth gathers (pixel 0 for lanes without a pixel), then the voxel
+//     reads of the survivors;
 //   * t = depth - cam.z decides cheaply what the reference computes through diff = t * sqrt(1 + (x/z)^2 + (y/z)^2):
 //     since that factor is >= 1, t <= -mu means diff <= -mu (skip, no voxel access) and t >= mu means
-//     diff / mu >= 1, i.e. sdf == 1.0f exactly; only the band |t| < mu needs the two divisions and the square root.
+//     diff / mu >= 1, i.e. sdf == 1.0f exactly; only the band |t| < mu needs the two divisions and the square root;
+//   * free space that has only ever been free space (stored 32766, sdf 1) keeps its 32766 for every weight: only the weight moves.
 // Every decision and every stored short is the one the CPU loop produces.
 // =====================================================================================
 
