@@ -12,6 +12,9 @@ namespace kf {
 #ifndef KFH_RAY_PROBES
 #define KFH_RAY_PROBES 0
 #endif
+#ifndef KFH_RAY_PREFETCH
+#define KFH_RAY_PREFETCH 1
+#endif
 
 template <int FD>
 struct VolViewT {
@@ -234,12 +237,13 @@ __device__ __forceinline__ BrickRay brick_ray(const SkipGrid &g, f3 origin, f3 d
     r.d = mk3(dir.x * g.kx, dir.y * g.ky, dir.z * g.kz);
     return r;
 }
-__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const BrickRay &r, float t) {
+__device__ __forceinline__ unsigned char brick_flag_at(const SkipGrid &g, const BrickRay &r, float t) {
     const unsigned bx = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.x, t, r.o.x), 0.f, g.bx_max);
     const unsigned by = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.y, t, r.o.y), 0.f, g.by_max);
     const unsigned bz = (unsigned)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(r.d.z, t, r.o.z), 0.f, g.bz_max);
-    return g.flags[__umul24(__umul24(bz, (unsigned)g.nby) + by, (unsigned)g.nbx) + bx] == 0;
+    return g.flags[__umul24(__umul24(bz, (unsigned)g.nby) + by, (unsigned)g.nbx) + bx];
 }
+__device__ __forceinline__ bool brick_is_empty(const SkipGrid &g, const BrickRay &r, float t) { return brick_flag_at(g, r, t) == 0; }
 
 // full rebuild (after reset or when a volume is injected from the host)
 __global__ __launch_bounds__(256) void k_build_skip_grid(unsigned char *__restrict__ flags, const short2 *__restrict__ vol,
@@ -394,16 +398,36 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
     bool lazy = false;           // f_t lies in an empty brick: >= 0.81, value not evaluated
     float f_t = 0.f, t_ft = t;
     bool first = true;
+#if KFH_RAY_PREFETCH
+    // The brick flag of a sample is requested one round ahead: if this round's Q samples are all plain "continue", the next
+    // round's times follow from this round's alone (last time + step, then the lanes' own additions), so their flags are in
+    // flight while this round's samples are taken - one dependent round trip per round instead of two.  A round that ends in
+    // an event (step switch) recomputes times and flags.
+    float tq = t;
+#pragma unroll
+    for (int i = 0; i < Q - 1; ++i) tq = (i < q) ? tq + stepsize : tq;
+    unsigned char fl = sg.flags ? brick_flag_at(sg, br, tq) : (unsigned char)1;
+#endif
     while (true) {
         work += Q;
+#if KFH_RAY_PREFETCH
+        const float t_last = group_last<Q>(tq, base);
+        float tqn = t_last + stepsize;
+#pragma unroll
+        for (int i = 0; i < Q - 1; ++i) tqn = (i < q) ? tqn + stepsize : tqn;
+        const unsigned char fln = sg.flags ? brick_flag_at(sg, br, tqn) : (unsigned char)1;
+#else
         float tq = t;
 #pragma unroll
         for (int i = 0; i < Q - 1; ++i) tq = (i < q) ? tq + stepsize : tq;
+#endif
         const bool in_range = tq < tfar;
         bool s_lazy = false;
         float f = 0.f;
         if (in_range) {
-#if KFH_RAY_PROBES
+#if KFH_RAY_PREFETCH
+            if (fl == 0) s_lazy = true;
+#elif KFH_RAY_PROBES
             if (sg.flags && (brick_is_empty(sg, br, tq) || (sg.probe & 4))) s_lazy = true;
 #else
             if (sg.flags && brick_is_empty(sg, br, tq)) s_lazy = true;
@@ -431,8 +455,13 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
             // forgive extra code.  profiles/r05_ab_ray_wide.txt)
             f_t = group_last<Q>(f, base);
             lazy = group_last<Q>((int)s_lazy, base) != 0;
+#if KFH_RAY_PREFETCH
+            t_ft = t_last;
+            tq = tqn; fl = fln;
+#else
             t_ft = group_last<Q>(tq, base);
             t = t_ft + stepsize;
+#endif
             continue;
         }
         const int e = __ffs(evmask) - 1;
@@ -456,6 +485,12 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
         f_t = fe;
         lazy = false;
         t = te + stepsize;
+#if KFH_RAY_PREFETCH
+        tq = t;
+#pragma unroll
+        for (int i = 0; i < Q - 1; ++i) tq = (i < q) ? tq + stepsize : tq;
+        fl = sg.flags ? brick_flag_at(sg, br, tq) : (unsigned char)1;
+#endif
     }
 }
 
