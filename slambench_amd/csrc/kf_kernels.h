@@ -197,7 +197,8 @@ void init_ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned n, hipSt
 void ray_order(unsigned *tile_order, unsigned *tile_cost, unsigned W, unsigned H, hipStream_t s);   // sort as a launch of its own
 void ray_tile_grid(unsigned W, unsigned H, unsigned *tiles_x, unsigned *tiles_y);
 bool ray_reorder_enabled();
-void copy_out(void *dst_pinned, const void *src, size_t bytes, unsigned blocks, hipStream_t s);     // bytes: a multiple of 16
+struct CopyOutSegments { uint4 *dst[3]; const uint4 *src[3]; size_t n16[3]; };      // dst: pinned host memory as the device sees it; n16: 16-byte pieces (0 = unused)
+void copy_out(const CopyOutSegments &g, unsigned blocks, hipStream_t s);
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s);
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,

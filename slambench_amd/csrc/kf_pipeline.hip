@@ -121,6 +121,7 @@ struct kfh_context {
     bool ray_maps_fresh = false;
     float ray_maps_largestep = 0.f;
     uchar4 *h_render_dev[3] = {nullptr, nullptr, nullptr};     // the same pinned staging buffers as the device sees them (render kernels of queued frames write there)
+    size_t rb_bytes[3] = {0, 0, 0};            // images rendered into d_render[] whose copy into the staging buffers has not been issued yet (issue_readback)
     std::vector<PendingCopy> pending;
     // optional HIP-event timing of pipeline phases (kfh_set_profiling)
     unsigned prof_mask = 0;
@@ -225,6 +226,7 @@ static bool launches_ok(kfh_context *c) {
 }
 
 static void finish_pending_frame(kfh_context *c, const struct NextFrameWork *next);
+static void issue_readback(kfh_context *c);
 static void refresh_mirror(kfh_context *c) {
     if (c->pend.valid) finish_pending_frame(c, nullptr);
     if (!c->mirror_stale) return;
@@ -889,6 +891,7 @@ void kfh_reset(kfh_context *c) { Entry e_(c);
 
 void kfh_synchronise(kfh_context *c) { Entry e_(c);
     flush_frame(c);
+    issue_readback(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->kernel_timings) prof_collect(c);
     flush_pending(c);
@@ -981,6 +984,7 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
                       uint32_t in_height, const float k[4], uint32_t integration_rate, uint32_t tracking_rate,
                       float icp_threshold, float mu, uint32_t frame) { Entry e_(c);
     if (!c || !depth_mm || !k || !integration_rate || !tracking_rate) return KFH_ERR_ARGUMENT;
+    issue_readback(c);       // the last frame's renders leave for the staging buffers in one launch
     const bool was_queued = true;
     if (!c->pipelined) {
         int r;
@@ -1018,6 +1022,30 @@ int kfh_compute_frame(kfh_context *c, const uint16_t *depth_mm, int32_t depth_is
     return c->error;   // KFH_OK, or what an EARLIER frame of this context left: queued frames report late (kfh_get_error after a sync is exact)
 }
 
+// Read-back of a queued frame's renders (copy kernel): the render calls only note which device images are due; the next call that
+// queues other work (kfh_compute_frame) or hands images over (kfh_synchronise) issues ONE copy kernel for all of them, in the compute
+// stream behind the render kernels - two launches fewer per rendered frame.  (On a stream of its own, beside the next frame's ICP
+// launches, the copy costs more than it hides - rounds 3 and 5, profiles/r05_sweeps.md.)
+static long render_copy_blocks() {
+    static const long copy_blocks = [] { const char *e = getenv("KFH_RENDER_COPY_KERNEL"); const long v = e ? atol(e) : 256L; return (v >= 0 && v <= 65535) ? v : 256L; }();
+    return copy_blocks;
+}
+static bool render_copy_batched() {
+    static const bool on = [] { const char *e = getenv("KFH_RENDER_COPY_BATCH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static void issue_readback(kfh_context *c) {
+    if (!(c->rb_bytes[0] | c->rb_bytes[1] | c->rb_bytes[2])) return;
+    launch::CopyOutSegments g = {};
+    for (int i = 0; i < 3; ++i) {
+        g.dst[i] = reinterpret_cast<uint4 *>(c->h_render_dev[i]);
+        g.src[i] = reinterpret_cast<const uint4 *>(c->d_render[i]);
+        g.n16[i] = c->rb_bytes[i] / 16;
+        c->rb_bytes[i] = 0;
+    }
+    launch::copy_out(g, (unsigned)render_copy_blocks(), c->stream);
+}
+
 // Where a render kernel writes, and how the image reaches the caller's buffer:
 //  * phase API (the benchmark driver, which synchronises right after the renders): device buffer, then one copy straight into the
 //    caller's (pageable) buffer - the runtime returns once it is there (rendering column of the driver 205 -> 122 us per frame);
@@ -1038,6 +1066,7 @@ static bool render_zero_copy(const kfh_context *c, int slot) {
 static void staging_free_for(kfh_context *c, int slot, const uint8_t *out) {
     for (const PendingCopy &p : c->pending)
         if (p.src == c->h_render[slot] && p.dst != out) {
+            issue_readback(c);
             HIP_TRY(hipStreamSynchronize(c->stream));
             flush_pending(c);
             break;
@@ -1062,10 +1091,15 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
         // The copy is a KERNEL of the compute stream that stores 16 bytes per lane into the pinned buffer (256 blocks: one per CU):
         // ~45 GB/s over PCIe and no copy-engine hand-over, against ~27 GB/s for hipMemcpyAsync at this size - fps_total 3485 -> 4050
         // at cfg2 (profiles/r05_copy_kernel.txt).  KFH_RENDER_COPY_KERNEL=<blocks> sets the grid, 0 = the copy engine.
-        static const long copy_blocks = [] { const char *e = getenv("KFH_RENDER_COPY_KERNEL"); const long v = e ? atol(e) : 256L; return (v >= 0 && v <= 65535) ? v : 256L; }();
-        if (copy_blocks > 0 && c->h_render_dev[slot] && bytes % 16 == 0)
-            launch::copy_out(c->h_render_dev[slot], c->d_render[slot], bytes, (unsigned)copy_blocks, c->stream);
-        else
+        const long copy_blocks = render_copy_blocks();
+        if (copy_blocks > 0 && c->h_render_dev[slot] && bytes % 16 == 0) {
+            if (render_copy_batched()) c->rb_bytes[slot] = bytes;      // issued with the frame's other images: issue_readback
+            else {
+                launch::CopyOutSegments g = {};
+                g.dst[0] = reinterpret_cast<uint4 *>(c->h_render_dev[slot]); g.src[0] = reinterpret_cast<const uint4 *>(c->d_render[slot]); g.n16[0] = bytes / 16;
+                launch::copy_out(g, (unsigned)copy_blocks, c->stream);
+            }
+        } else
             HIP_TRY(hipMemcpyAsync(c->h_render[slot], c->d_render[slot], bytes, hipMemcpyDeviceToHost, c->stream));
     }
     for (PendingCopy &p : c->pending) if (p.dst == out) { p.src = c->h_render[slot]; p.bytes = bytes; return; }

@@ -55,16 +55,23 @@ __global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, 
     out[x + y * W] = o;
 }
 
-// An image from HBM into pinned host memory by 16-byte stores over PCIe (the read-back of a queued frame's renders as a kernel of
-// the compute stream instead of a copy-engine command: KFH_RENDER_COPY_KERNEL, kf_pipeline.hip queue_readback)
-__global__ __launch_bounds__(256) void k_copy_out(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// Images from HBM into pinned host memory by 16-byte stores over PCIe (the read-back of a queued frame's renders as a kernel
+// instead of copy-engine commands: KFH_RENDER_COPY_KERNEL, kf_pipeline.hip queue_readback / issue_readback).  Up to three images
+// per launch, walked as one range of 16-byte pieces.
+__global__ __launch_bounds__(256) void k_copy_out(launch::CopyOutSegments g) {
+    const size_t total = g.n16[0] + g.n16[1] + g.n16[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t j = i;
+        int k = 0;
+        if (j >= g.n16[0]) { j -= g.n16[0]; k = 1; if (j >= g.n16[1]) { j -= g.n16[1]; k = 2; } }
+        g.dst[k][j] = g.src[k][j];
+    }
 }
 
 namespace launch {
 
-void copy_out(void *dst_pinned, const void *src, size_t bytes, unsigned blocks, hipStream_t s) {
-    k_copy_out<<<blocks, 256, 0, s>>>(static_cast<uint4 *>(dst_pinned), static_cast<const uint4 *>(src), bytes / 16); launched("k_copy_out");
+void copy_out(const CopyOutSegments &g, unsigned blocks, hipStream_t s) {
+    k_copy_out<<<blocks, 256, 0, s>>>(g); launched("k_copy_out");
 }
 
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {
