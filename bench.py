@@ -698,7 +698,7 @@ def measure(S, args, multi, config_name, steps, warmup, full):
             frames_r = max(1, launched["render_depth"])
             kern_us = sum(render_prof[k][0] for k in alg) / frames_r * 1e3
             images = sum(launched.values()) / frames_r
-            roof["render_readback"] = {"what": "device-to-host copies of the rendered images in the compute stream (hipMemcpyAsync into pinned staging)",
+            roof["render_readback"] = {"what": "the rendered images of a queued frame into pinned staging: one copy kernel per frame in the compute stream, 16-byte stores over PCIe",
                                        "bytes_per_frame": round(images * 4.0 * P), "images_per_frame": round(images, 2),
                                        "render_kernels_us_per_frame": round(kern_us, 2),
                                        "frame_us_with_renders": round(1e6 / fps_total, 2), "frame_us_without": round(t_max / (steps * spg) * 1e6, 2),

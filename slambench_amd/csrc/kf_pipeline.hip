@@ -42,6 +42,8 @@ static bool hip_ok(hipError_t e, const char *what, const char *file, int line) {
 #define HIP_TRY(x) hip_ok((x), #x, __FILE__, __LINE__)
 
 struct PendingCopy { void *dst; const void *src; size_t bytes; };
+// a render asked for while a queued frame's second part is still deferred (run_deferred_renders)
+struct DeferredRender { int kind; uint8_t *out; uint32_t w, h; int32_t frame; float k[4]; float largestep; };
 
 struct kfh_context {
     // Every C-ABI entry that takes a context holds this lock for its duration, and so does kfh_synchronise_all() for each context it
@@ -121,6 +123,7 @@ struct kfh_context {
     bool ray_maps_fresh = false;
     float ray_maps_largestep = 0.f;
     uchar4 *h_render_dev[3] = {nullptr, nullptr, nullptr};     // the same pinned staging buffers as the device sees them (render kernels of queued frames write there)
+    std::vector<DeferredRender> deferred_renders;
     size_t rb_bytes[3] = {0, 0, 0};            // images rendered into d_render[] whose copy into the staging buffers has not been issued yet (issue_readback)
     std::vector<PendingCopy> pending;
     // optional HIP-event timing of pipeline phases (kfh_set_profiling)
@@ -227,6 +230,7 @@ static bool launches_ok(kfh_context *c) {
 
 static void finish_pending_frame(kfh_context *c, const struct NextFrameWork *next);
 static void issue_readback(kfh_context *c);
+static void run_deferred_renders(kfh_context *c);
 static void refresh_mirror(kfh_context *c) {
     if (c->pend.valid) finish_pending_frame(c, nullptr);
     if (!c->mirror_stale) return;
@@ -567,6 +571,8 @@ static void finish_pending_frame(kfh_context *c, const NextFrameWork *next) {
         c->pend.valid = false;
         c->mirror_stale = true;
     }
+    // the renders asked for since the frame was queued: behind its raycast, before the double buffers of the input maps change hands
+    if (!c->deferred_renders.empty()) run_deferred_renders(c);
     if (!next) return;
     if (next_done) {
         // the side jobs wrote the other half of the double buffer: it now holds the newest frame
@@ -853,6 +859,7 @@ void kfh_destroy(kfh_context *c) {
     }
     hipSetDevice(c->device);
     c->pend.valid = false;   // a frame still deferred is dropped with the context
+    c->deferred_renders.clear();
     if (c->stream) hipStreamSynchronize(c->stream);
     c->pending.clear();      // render read-backs nobody synchronised for are dropped: the caller's buffers may be gone by now
     hipFree(c->d_input); hipFree(c->d_floatDepth);
@@ -1107,29 +1114,34 @@ static void queue_readback(kfh_context *c, int slot, uint8_t *out, uint32_t w, u
     c->pending.push_back(p);
 }
 
-void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
-    if (!c || !out || w != c->W || h != c->H) return;
-    flush_frame(c);
+// Renders of queued frames.  A render called while the frame's second part is still deferred (kfh_compute_frame, then the renders, then
+// the next kfh_compute_frame: bench.py's fps_total loop, a GUI that does not wait) used to close the frame on the spot - and with it
+// the chance of the NEXT frame's preprocessing to ride on this frame's ICP launches: 25 us of stand-alone launches per frame at 640x480.
+// Now the request is noted and carried out by whoever closes the frame (finish_pending_frame: the next kfh_compute_frame, or any call
+// that needs the frame's result), right behind its raycast - the same images, since no call can change what a render reads without
+// closing the frame first.  KFH_RENDER_DEFER=0: close the frame at once, as before.
+static bool defer_render(kfh_context *c, const DeferredRender &r) {
+    const char *e = getenv("KFH_RENDER_DEFER");      // (read per call: the parity test switches it inside one process)
+    if ((e && e[0] == '0') || !c->pipelined || !c->queued_api || !c->pend.valid) return false;
+    c->deferred_renders.push_back(r);
+    return true;
+}
+
+static void render_depth_now(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     prof_begin(c, KFH_PROF_RENDER_DEPTH);
     launch::render_depth(render_target(c, 0, out), c->d_floatDepth, w, h, nearPlane, farPlane, c->stream);
     prof_end(c, KFH_PROF_RENDER_DEPTH);
     queue_readback(c, 0, out, w, h);
 }
 
-void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
-    if (!c || !out || w != c->W || h != c->H) return;
-    flush_frame(c);
+static void render_track_now(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) {
     prof_begin(c, KFH_PROF_RENDER_TRACK);
     launch::render_track(render_target(c, 1, out), c->d_result, w, h, c->stream);
     prof_end(c, KFH_PROF_RENDER_TRACK);
     queue_readback(c, 1, out, w, h);
 }
 
-void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, int32_t rate, const float k[4],
-                       float largestep) { Entry e_(c);
-    if (!c || !out || !k || w != c->W || h != c->H || rate == 0) return;
-    flush_frame(c);
-    if (frame % rate != 0) return;   // cpp:1034
+static void render_volume_now(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, const float k[4], float largestep) {
     ControlArgs a;
     fill_control(c, a, k, (unsigned)frame, 1, 1);
     launch::control(c->d_state, c->d_log, OP_RENDER_BEGIN, a, c->stream);
@@ -1145,6 +1157,50 @@ void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int
                           reuse ? c->d_vertex : nullptr, reuse ? c->d_normal : nullptr, reuse ? &c->d_state->ray : nullptr, farPlane, c->stream);
     prof_end(c, KFH_PROF_RENDER_VOLUME);
     queue_readback(c, 2, out, w, h);
+}
+
+static void run_deferred_renders(kfh_context *c) {
+    std::vector<DeferredRender> list;
+    list.swap(c->deferred_renders);
+    const bool prof_now = c->prof_now;
+    const int prof_only = c->prof_only;
+    c->prof_now = true; c->prof_only = -1;       // renders are always timed when their phase is enabled (flush_frame)
+    for (const DeferredRender &r : list) {
+        if (r.kind == 0) render_depth_now(c, r.out, r.w, r.h);
+        else if (r.kind == 1) render_track_now(c, r.out, r.w, r.h);
+        else render_volume_now(c, r.out, r.w, r.h, r.frame, r.k, r.largestep);
+    }
+    c->prof_now = prof_now; c->prof_only = prof_only;
+    issue_readback(c);
+}
+
+void kfh_render_depth(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
+    if (!c || !out || w != c->W || h != c->H) return;
+    DeferredRender r = {0, out, w, h, 0, {0, 0, 0, 0}, 0.f};
+    if (defer_render(c, r)) return;
+    flush_frame(c);
+    render_depth_now(c, out, w, h);
+}
+
+void kfh_render_track(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h) { Entry e_(c);
+    if (!c || !out || w != c->W || h != c->H) return;
+    DeferredRender r = {1, out, w, h, 0, {0, 0, 0, 0}, 0.f};
+    if (defer_render(c, r)) return;
+    flush_frame(c);
+    render_track_now(c, out, w, h);
+}
+
+void kfh_render_volume(kfh_context *c, uint8_t *out, uint32_t w, uint32_t h, int32_t frame, int32_t rate, const float k[4],
+                       float largestep) { Entry e_(c);
+    if (!c || !out || !k || w != c->W || h != c->H || rate == 0) return;
+    if (frame % rate != 0) {   // cpp:1034
+        if (!c->pend.valid || c->deferred_renders.empty()) flush_frame(c);      // (as before - unless renders are waiting for the frame to close)
+        return;
+    }
+    DeferredRender r = {2, out, w, h, frame, {k[0], k[1], k[2], k[3]}, largestep};
+    if (defer_render(c, r)) return;
+    flush_frame(c);
+    render_volume_now(c, out, w, h, frame, k, largestep);
 }
 
 int kfh_dump_volume(kfh_context *c, const char *filename) { Entry e_(c);

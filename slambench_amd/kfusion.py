@@ -121,6 +121,17 @@ class Kfusion:
         self.synchronise()
         return buf
 
+    def queue_renders(self, depth_out, track_out, volume_out, frame, rate, k, largestep):
+        """The three renders of the frame just queued, without waiting for them: `*_out` are (H, W, 4) uint8 arrays the caller keeps
+        alive; they hold the images after the next synchronise() (after a kfh_compute_frame the renders are carried out by the
+        call that closes the frame - the next compute_frame - so that its preprocessing still rides on this frame's ICP launches)."""
+        u8 = C.POINTER(C.c_uint8)
+        for a in (depth_out, track_out, volume_out):
+            assert a.dtype == np.uint8 and a.flags.c_contiguous and a.shape == (self.H, self.W, 4)
+        self.L.kfh_render_depth(self.h, depth_out.ctypes.data_as(u8), self.W, self.H)
+        self.L.kfh_render_track(self.h, track_out.ctypes.data_as(u8), self.W, self.H)
+        self.L.kfh_render_volume(self.h, volume_out.ctypes.data_as(u8), self.W, self.H, frame, rate, _capi.f32(k), largestep)
+
     def dump_volume(self, filename):
         return self.L.kfh_dump_volume(self.h, filename.encode() if filename else None)
 

@@ -291,3 +291,69 @@ def test_render_volume_from_the_frames_raycast_equals_the_march(hip, kfmod, orc,
     assert (vz[:, W // 2 + 8:] == 0).mean() > 0.9 and (vz[:, : W // 2 - 8] > 0).mean() > 0.9      # the far half misses in the tracking raycast ...
     assert (img[:, W // 2 + 8:, :3].max(axis=-1) > 0).mean() > 0.9                                 # ... and is there in the rendering
     g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_renders_of_queued_frames_carried_out_by_the_call_that_closes_the_frame(hip, kfmod, orc, monkeypatch):
+    """kfh_compute_frame, the three renders, the next kfh_compute_frame ... without a synchronisation in between (bench.py's fps_total
+    loop): the renders are noted and carried out behind the frame's raycast by the call that closes the frame, so that the next
+    frame's preprocessing still rides on this frame's ICP launches (KFH_RENDER_DEFER).  Same images, poses, volume and frame log as
+    with the frame closed at every render (KFH_RENDER_DEFER=0); images against the oracle's renders; with one set of buffers for
+    all frames (nothing waits), with buffers of their own per frame (every frame's images are delivered), and with a getter between
+    the renders (which closes the frame: the renders already noted are carried out, the one after it runs at once)."""
+    n = 9
+    s = synth.make_stream(n, W, H)
+    k = list(s.k)
+    res = (128, 128, 128)
+    ls = 0.75 * util.MU
+
+    def run(defer, own_buffers, getter_between=False):
+        if defer: monkeypatch.delenv("KFH_RENDER_DEFER", raising=False)
+        else: monkeypatch.setenv("KFH_RENDER_DEFER", "0")
+        g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+        imgs = [[np.full((H, W, 4), 7, np.uint8) for _ in range(3)] for _ in range(n if own_buffers else 1)]
+        for f in range(n):
+            g.compute_frame(s.depth_mm[f], (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+            b = imgs[f if own_buffers else 0]
+            if getter_between and f == 5:
+                import ctypes as C
+                g.L.kfh_render_depth(g.h, b[0].ctypes.data_as(C.POINTER(C.c_uint8)), W, H)
+                pose_mid = g.get_pose()          # closes the frame: the depth render is carried out, pose of frame 5
+                g.L.kfh_render_track(g.h, b[1].ctypes.data_as(C.POINTER(C.c_uint8)), W, H)
+                g.L.kfh_render_volume(g.h, b[2].ctypes.data_as(C.POINTER(C.c_uint8)), W, H, f, 1, (C.c_float * 4)(*k), ls)
+            else:
+                g.queue_renders(b[0], b[1], b[2], f, 1, k, ls)
+        g.synchronise()
+        out = dict(imgs=imgs, pose=g.get_pose(), vol=g.buffer("volume").copy(), log=g.frame_log(n))
+        g.close()
+        return out
+
+    ref = run(False, True)
+    for own, getter in ((True, False), (False, False), (True, True)):
+        got = run(True, own, getter)
+        assert same_bits(got["pose"], ref["pose"]) and np.array_equal(got["vol"], ref["vol"]), (own, getter)
+        assert all(np.array_equal(a, b) for a, b in zip(got["log"], ref["log"]))
+        if own:
+            for f in range(n):
+                for i in range(3):
+                    assert np.array_equal(got["imgs"][f][i], ref["imgs"][f][i]), (f, i, getter)
+        else:
+            for i in range(3):
+                assert np.array_equal(got["imgs"][0][i], ref["imgs"][n - 1][i]), i
+    assert ref["imgs"][n - 1][2][..., :3].max() > 0 and ref["imgs"][n - 1][0][..., :3].max() > 0
+    # ... and the images themselves against the oracle, frame by frame along the HIP trajectory (poses injected, as in the lock-step tests)
+    o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
+    g = kfmod.Kfusion((W, H), res, util.VOL_DIM, s.init_pos)
+    for f in range(n):
+        o.set_pose(g.get_pose())
+        g.compute_frame(s.depth_mm[f], (W, H), k, 2, 1, util.ICP_THRESHOLD, util.MU, f)
+        b = [np.zeros((H, W, 4), np.uint8) for _ in range(3)]
+        g.queue_renders(b[0], b[1], b[2], f, 1, k, ls)
+        g.synchronise()
+        o.preprocessing(s.depth_mm[f]); o.tracking(k, util.ICP_THRESHOLD, 1, f)
+        o.set_pose(g.get_pose())
+        o.integration(k, 2, util.MU, f); o.raycasting(k, util.MU, f)
+        assert np.array_equal(b[0], o.render_depth()), f
+        assert np.array_equal(b[2], o.render_volume(f, 1, k, ls)), f
+        assert np.array_equal(b[0], ref["imgs"][f][0]) and np.array_equal(b[2], ref["imgs"][f][2]), f
+    g.close(); o.close()
