@@ -201,6 +201,8 @@ struct CopyOutSegments { uint4 *dst[3]; const uint4 *src[3]; size_t n16[3]; };  
 void copy_out(const CopyOutSegments &g, unsigned blocks, hipStream_t s);
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s);
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s);
+void render_depth_track(uchar4 *out_depth, const float *depth, uchar4 *out_track, const int *result_map, unsigned W, unsigned H,
+                        float nearPlane, float farPlane, hipStream_t s);      // both in one launch
 void render_volume(uchar4 *out, unsigned W, unsigned H, const int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim,
                    const RayParams *p, float nearPlane, float farPlane, float step, float largestep, f3 light, f3 ambient,
                    const unsigned char *skip_flags, const float4 *seen_vertex, const float4 *seen_normal, const RayParams *seen_rp, float seen_far_plane,

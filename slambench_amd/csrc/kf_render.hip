@@ -23,8 +23,8 @@ __device__ __forceinline__ uchar4 gs2rgb(double h) {
     return make_uchar4((unsigned char)(r * 255), (unsigned char)(g * 255), (unsigned char)(b * 255), 0);
 }
 
-__global__ __launch_bounds__(256) void k_render_depth(uchar4 *__restrict__ out, const float *__restrict__ depth,
-                                                      unsigned W, unsigned H, float nearPlane, float farPlane) {
+__device__ __forceinline__ void render_depth_pixel(uchar4 *__restrict__ out, const float *__restrict__ depth, unsigned W, unsigned H,
+                                                   float nearPlane, float farPlane) {
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     const float rangeScale = 1 / (farPlane - nearPlane);
@@ -38,8 +38,7 @@ __global__ __launch_bounds__(256) void k_render_depth(uchar4 *__restrict__ out, 
 }
 
 // renderTrackKernel (cpp:844-878) on the int32 result map the fused ICP pass keeps
-__global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, const int *__restrict__ result,
-                                                      unsigned W, unsigned H) {
+__device__ __forceinline__ void render_track_pixel(uchar4 *__restrict__ out, const int *__restrict__ result, unsigned W, unsigned H) {
     const unsigned x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     uchar4 o;
@@ -53,6 +52,24 @@ __global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, 
     default: o = make_uchar4(255, 128, 128, 0); break;
     }
     out[x + y * W] = o;
+}
+
+__global__ __launch_bounds__(256) void k_render_depth(uchar4 *__restrict__ out, const float *__restrict__ depth,
+                                                      unsigned W, unsigned H, float nearPlane, float farPlane) {
+    render_depth_pixel(out, depth, W, H, nearPlane, farPlane);
+}
+
+__global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, const int *__restrict__ result,
+                                                      unsigned W, unsigned H) {
+    render_track_pixel(out, result, W, H);
+}
+
+// both images of a queued frame in one launch (kf_pipeline.hip run_deferred_renders): blockIdx.z = 0 depth, 1 track
+__global__ __launch_bounds__(256) void k_render_depth_track(uchar4 *__restrict__ out_depth, const float *__restrict__ depth,
+                                                            uchar4 *__restrict__ out_track, const int *__restrict__ result,
+                                                            unsigned W, unsigned H, float nearPlane, float farPlane) {
+    if (blockIdx.z == 0) render_depth_pixel(out_depth, depth, W, H, nearPlane, farPlane);
+    else render_track_pixel(out_track, result, W, H);
 }
 
 // Images from HBM into pinned host memory by 16-byte stores over PCIe (the read-back of a queued frame's renders as a kernel
@@ -76,6 +93,12 @@ void copy_out(const CopyOutSegments &g, unsigned blocks, hipStream_t s) {
 
 void render_depth(uchar4 *out, const float *depth, unsigned W, unsigned H, float nearPlane, float farPlane, hipStream_t s) {
     k_render_depth<<<grid_rows(W, H), block_rows(), 0, s>>>(out, depth, W, H, nearPlane, farPlane); launched("k_render_depth");
+}
+
+void render_depth_track(uchar4 *out_depth, const float *depth, uchar4 *out_track, const int *result_map, unsigned W, unsigned H,
+                        float nearPlane, float farPlane, hipStream_t s) {
+    const dim3 g = grid_rows(W, H);
+    k_render_depth_track<<<dim3(g.x, g.y, 2), block_rows(), 0, s>>>(out_depth, depth, out_track, result_map, W, H, nearPlane, farPlane); launched("k_render_depth_track");
 }
 
 void render_track(uchar4 *out, const int *result_map, unsigned W, unsigned H, hipStream_t s) {
