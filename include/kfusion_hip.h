@@ -99,7 +99,9 @@ int kfh_compute_frame(kfh_context *ctx, const uint16_t *depth_mm, int32_t depth_
                       float icp_threshold, float mu, uint32_t frame);
 
 /* void Kfusion::renderDepth/renderTrack/renderVolume(uchar4* out, uint2 outputSize, ...)  cpp/kernels.cpp:1032-1046
- * `out` is host memory (width*height*4 bytes); it is complete after kfh_synchronise(). */
+ * `out` is host memory (width*height*4 bytes) that stays valid until then; it is complete after kfh_synchronise().
+ * After kfh_compute_frame() the renders show that frame: they are carried out when its deferred second part is (the next
+ * kfh_compute_frame(), or any call that needs the frame's result), right behind its raycast. */
 void kfh_render_depth(kfh_context *ctx, uint8_t *out_rgba, uint32_t width, uint32_t height);
 void kfh_render_track(kfh_context *ctx, uint8_t *out_rgba, uint32_t width, uint32_t height);
 void kfh_render_volume(kfh_context *ctx, uint8_t *out_rgba, uint32_t width, uint32_t height, int32_t frame,
