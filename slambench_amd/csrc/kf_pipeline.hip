@@ -1259,6 +1259,7 @@ int kfh_get_error(kfh_context *c) { Entry e_(c);
     return c->error;
 }
 void kfh_set_view_pose(kfh_context *c, const float *vp) { Entry e_(c);   // kernels.h:179-184
+    if (c && !c->deferred_renders.empty()) flush_frame(c);      // renders already asked for show the view as it was when they were asked for
     if (vp) { std::memcpy(&c->viewPose, vp, sizeof(M4)); c->useViewPose = true; }
     else c->useViewPose = false;
 }

@@ -307,6 +307,8 @@ def test_renders_of_queued_frames_carried_out_by_the_call_that_closes_the_frame(
     res = (128, 128, 128)
     ls = 0.75 * util.MU
 
+    ref_pose6 = None
+
     def run(defer, own_buffers, getter_between=False):
         if defer: monkeypatch.delenv("KFH_RENDER_DEFER", raising=False)
         else: monkeypatch.setenv("KFH_RENDER_DEFER", "0")
@@ -323,14 +325,23 @@ def test_renders_of_queued_frames_carried_out_by_the_call_that_closes_the_frame(
                 g.L.kfh_render_volume(g.h, b[2].ctypes.data_as(C.POINTER(C.c_uint8)), W, H, f, 1, (C.c_float * 4)(*k), ls)
             else:
                 g.queue_renders(b[0], b[1], b[2], f, 1, k, ls)
+            if getter_between and f == 6:        # a view pose of the caller's from frame 7 on: frame 6's renders were asked for before it
+                view = np.array(ref_pose6, np.float32).copy()
+                view[0, 3] += 0.05
+                g.set_view_pose(view)
         g.synchronise()
         out = dict(imgs=imgs, pose=g.get_pose(), vol=g.buffer("volume").copy(), log=g.frame_log(n))
         g.close()
         return out
 
     ref = run(False, True)
+    ref_pose6 = ref["log"][0][6]
+    ref_extras = run(False, True, True)
+    assert not np.array_equal(ref_extras["imgs"][7][2], ref["imgs"][7][2]) and np.array_equal(ref_extras["imgs"][6][2], ref["imgs"][6][2])
     for own, getter in ((True, False), (False, False), (True, True)):
         got = run(True, own, getter)
+        plain = ref
+        ref = ref_extras if getter else plain
         assert same_bits(got["pose"], ref["pose"]) and np.array_equal(got["vol"], ref["vol"]), (own, getter)
         assert all(np.array_equal(a, b) for a, b in zip(got["log"], ref["log"]))
         if own:
@@ -340,6 +351,7 @@ def test_renders_of_queued_frames_carried_out_by_the_call_that_closes_the_frame(
         else:
             for i in range(3):
                 assert np.array_equal(got["imgs"][0][i], ref["imgs"][n - 1][i]), i
+        ref = plain
     assert ref["imgs"][n - 1][2][..., :3].max() > 0 and ref["imgs"][n - 1][0][..., :3].max() > 0
     # ... and the images themselves against the oracle, frame by frame along the HIP trajectory (poses injected, as in the lock-step tests)
     o = orc.OracleKfusion((W, H), res, util.VOL_DIM, s.init_pos, omp=True)
