@@ -1038,8 +1038,8 @@ static long render_copy_blocks() {
     return copy_blocks;
 }
 static bool render_copy_batched() {
-    static const bool on = [] { const char *e = getenv("KFH_RENDER_COPY_BATCH"); return !(e && e[0] == '0'); }();
-    return on;
+    const char *e = getenv("KFH_RENDER_COPY_BATCH");      // (read per call: the parity test switches it inside one process)
+    return !(e && e[0] == '0');
 }
 static void issue_readback(kfh_context *c) {
     if (!(c->rb_bytes[0] | c->rb_bytes[1] | c->rb_bytes[2])) return;
@@ -1080,6 +1080,9 @@ static void staging_free_for(kfh_context *c, int slot, const uint8_t *out) {
         }
 }
 static uchar4 *render_target(kfh_context *c, int slot, const uint8_t *out) {
+    // an image of this kind whose copy has not been issued yet (two renders of a kind without a kfh_compute_frame or a synchronisation
+    // in between - e.g. a queued frame's render, then a frame through the phase calls): it leaves before the kernel overwrites it
+    if (c->rb_bytes[slot]) issue_readback(c);
     if (!render_zero_copy(c, slot)) return c->d_render[slot];
     staging_free_for(c, slot, out);
     return c->h_render_dev[slot];
