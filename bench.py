@@ -30,6 +30,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -235,6 +236,12 @@ def timed_run(S, make_leg, multi, n_warm, n_steps, prof_every):
         if err is not None:
             print("bench.py: rank %d failed before the timed region: %r" % (S.rank, err), file=sys.stderr)
         raise SystemExit(1)
+    # (the collector stays out of the timed region, as timeit keeps it: one full collection of a process that has torch loaded is a
+    # 40-45 ms pause of the thread that queues the frames - found inside a render call of the first rendered leg of a process, where
+    # it turned 4500 frames/s into 2400, profiles/r05_host_stalls.txt - and when it comes depends on what the imports allocated)
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     S.device_sync()
     if S.dist is not None:
         S.dist.barrier()
@@ -247,6 +254,8 @@ def timed_run(S, make_leg, multi, n_warm, n_steps, prof_every):
         err = e
     S.device_sync()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     if S.dist is not None:
         S.dist.barrier()
     return elapsed, leg, err
@@ -599,8 +608,9 @@ def measure(S, args, multi, config_name, steps, warmup, full):
         j = multi.aggregate(multi.RankStats(steps, e, failed=0 if err is None else 1), dist, device=S.coll_device)
         return (None, "%d rank(s) failed%s" % (j.failed, ": %r" % (err,) if err is not None else "")) if j.failed else (j.fps, None)
 
-    # A throw-away leg first: the very first leg of a process starts from an idle-clocked GPU and came out 15-25 % low for it
-    # (fps_total 2400-2560 as the first leg against 2990-3200 otherwise, profiles/r03_render_async_ab.txt).  Not timed, not reported.
+    # A throw-away leg first, so that the first measured leg does not start from an idle-clocked GPU.  Not timed, not reported.
+    # (Rounds 3-5 blamed it for a first rendered leg that came out 15-40 % low - fps_total 2400-3200 against 4000+ in later
+    # processes; that was the Python collector's first full collection, which timed_run now keeps out of the timed region.)
     if full and not S.dry and not args.no_preheat:
         _, pre, perr = timed_run(S, lambda: mk(False), multi, min(warmup, 8), min(60, steps), 0)
         if pre is not None:
