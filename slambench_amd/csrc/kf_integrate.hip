@@ -73,6 +73,25 @@ template <bool KZ> __device__ __forceinline__ float cam_z(const ColumnState &S) 
 __device__ __forceinline__ void store_voxel(short2 *vol, unsigned byte_offset, unsigned value) {
     *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(vol) + byte_offset) = value;
 }
+// Per-batch wall-clock stamps of every wave for the KFH_INTEGRATE_TRACE dump (profiles/int_stamps.py): ONLY in a build with
+// -DKFH_INT_STAMPS=1; a record is then 32 words per wave - {start, end, work, block, after the head, after the replay, the start of each
+// batch with the stage the previous batch reached in the top bits (1 detailed pass, 2 depth classification, 3 update), end of the loop}.
+#ifndef KFH_INT_STAMPS
+#define KFH_INT_STAMPS 0
+#endif
+constexpr unsigned INT_TRACE_WORDS = KFH_INT_STAMPS ? 32u : 4u;
+#if KFH_INT_STAMPS
+#define KFH_INT_STAMP(slot, tag)                                                                                               \
+    do {                                                                                                                      \
+        if (trace) {                                                                                                          \
+            const unsigned long long t_ = wall_clock64() | ((unsigned long long)(tag) << 60);                                 \
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.x) == threadIdx.x && (slot) < 32u)                     \
+                trace[(size_t)INT_TRACE_WORDS * (slot_id * 4 + threadIdx.y) + (slot)] = t_;                                    \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define KFH_INT_STAMP(slot, tag) do { } while (0)
+#endif
 #ifndef KFH_INTEGRATE_WAVES_PER_SIMD
 #define KFH_INTEGRATE_WAVES_PER_SIMD 5      // occupancy floor handed to the register allocator (5 = at most 96 VGPRs)
 #endif
@@ -88,6 +107,10 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
     // (gate, matrices, bounds) and its entry of the dispatch order - is requested in one go: written in the order of use
     // these are five dependent scalar round trips, ~1.5 us at the head of every wave, two thirds of which leave right after
     const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#if KFH_INT_STAMPS
+    const unsigned slot_id = slot;
+    unsigned stage_reached = 0;
+#endif
     const IntegrateParams P = *ip;
     const unsigned vb = order ? order[slot] : slot;
     // (the empty statement "uses" one word of every piece the structure is fetched in, so that the compiler cannot put the
@@ -148,6 +171,7 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             chunk_out = chunk_out || behind;
         }
+        KFH_INT_STAMP(4u, 0);
         if (!chunk_out) {      // (eight steps per trip: as a plain loop every step pays the loop's scalar bookkeeping too)
             unsigned z = 0;
             for (; z + 8 <= z0; z += 8) {
@@ -186,9 +210,17 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             return e;
         };
         EndPoint ep = end_point(S);
+        KFH_INT_STAMP(5u, 0);
         if (!chunk_out)
         for (unsigned zb = z0; zb < z1; zb += IB, voff += (unsigned)IB * plane4) {
             const unsigned nb = (z1 - zb) < (unsigned)IB ? (z1 - zb) : (unsigned)IB;
+#if KFH_INT_STAMPS
+            {
+                const unsigned reached = __builtin_amdgcn_ballot_w64(stage_reached >= 3u) ? 3u : (__builtin_amdgcn_ballot_w64(stage_reached >= 2u) ? 2u : (__builtin_amdgcn_ballot_w64(stage_reached >= 1u) ? 1u : 0u));
+                KFH_INT_STAMP(6u + (zb - z0) / (unsigned)IB, reached);
+                stage_reached = 0;
+            }
+#endif
             const ColumnState first = S;
             // advance over the batch: S becomes the state of the next batch's first voxel
             if (nb == (unsigned)IB) {   // whole batch (all but possibly the last of a chunk): straight-line packed adds
@@ -215,6 +247,9 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             // (5x that) of an integer it gives the same decisions and the same integer; the IEEE divisions run only for those rare
             // pixels (a wave-level branch).  Values far outside are clamped to -1.5 / size + 0.5 first - half-integers, so never "near an
             // integer", and on the same side of 0 and size - 1 as the value itself.
+#if KFH_INT_STAMPS
+            stage_reached = 1;
+#endif
             ColumnState T = first;
             unsigned live = 0;            // bit i: voxel zb+i projects into the image
             unsigned pix[IB];             // byte offset of its pixel in the depth image
@@ -242,6 +277,9 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             ++work;
             if (!live || KFH_INT_PROBE(2)) continue;
             // t = depth - cam.z: <= -mu -> rejected by cpp:662; >= mu -> sdf == 1; in between -> full formula
+#if KFH_INT_STAMPS
+            stage_reached = 2;
+#endif
             unsigned need = 0;
             float t_[IB];
             {
@@ -259,6 +297,9 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
             if (!need || KFH_INT_PROBE(4)) continue;
             work += 4;
+#if KFH_INT_STAMPS
+            stage_reached = 3;
+#endif
             unsigned c[IB];               // the voxels as stored: tsdf short in the low half, weight in the high half
 #pragma unroll
             for (int i = 0; i < IB; ++i)
@@ -310,6 +351,12 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
             }
         }
     }
+#if KFH_INT_STAMPS
+    {
+        const unsigned reached = __builtin_amdgcn_ballot_w64(stage_reached >= 3u) ? 3u : (__builtin_amdgcn_ballot_w64(stage_reached >= 2u) ? 2u : (__builtin_amdgcn_ballot_w64(stage_reached >= 1u) ? 1u : 0u));
+        KFH_INT_STAMP(31u, reached);
+    }
+#endif
     // two of three waves examined nothing (their chunks lie outside the frustum): nothing to add to the cost table or the
     // counter, so they leave here instead of running two six-step wave reductions over zeros
     if (!trace && __builtin_amdgcn_ballot_w64((work | updated) != 0u) == 0ull) return;
@@ -319,8 +366,8 @@ __global__ __launch_bounds__(256, IB <= 8 ? KFH_INTEGRATE_WAVES_PER_SIMD : 1) vo
         if (cost && threadIdx.x == 0 && work) atomicMax(cost + vb, work);
     }
     if (trace && threadIdx.x == 0) {   // debugging (KFH_INTEGRATE_TRACE): per wave {start, end, cost, block}
-        const unsigned wave = slot * 4 + threadIdx.y;
-        trace[4 * wave] = t_start; trace[4 * wave + 1] = wall_clock64(); trace[4 * wave + 2] = work; trace[4 * wave + 3] = vb;
+        const size_t wave = (size_t)INT_TRACE_WORDS * (slot * 4 + threadIdx.y);
+        trace[wave] = t_start; trace[wave + 1] = wall_clock64(); trace[wave + 2] = work; trace[wave + 3] = vb;
     }
     // instrumentation (U = voxels that passed all four tests): one atomic per wave
     if (updated_total) {
@@ -371,7 +418,7 @@ void integrate(int16_t *vol, unsigned sx, unsigned sy, unsigned sz, f3 dim, cons
     const dim3 grid = integrate_grid(sx, sy, sz, &zchunk);
     short2 *v = reinterpret_cast<short2 *>(vol);
     static WaveTrace wt("KFH_INTEGRATE_TRACE");
-    unsigned long long *trace = wt.arm((size_t)grid.x * grid.y * grid.z * 4, s);
+    unsigned long long *trace = wt.arm((size_t)grid.x * grid.y * grid.z * 4 * (INT_TRACE_WORDS / 4), s);
     const bool reorder = integrate_reorder_enabled() && block_order && block_cost;
     const unsigned *order = reorder ? block_order : nullptr;
     unsigned *cost = reorder ? block_cost : nullptr;
