@@ -380,10 +380,13 @@ __device__ __forceinline__ int group_last(int x, int base) {
 template <int Q> __device__ __forceinline__ float group_first(float x, int base) { return __builtin_bit_cast(float, group_first<Q>(__builtin_bit_cast(int, x), base)); }
 template <int Q> __device__ __forceinline__ float group_last(float x, int base) { return __builtin_bit_cast(float, group_last<Q>(__builtin_bit_cast(int, x), base)); }
 
+// Returns the ray parameter of the hit (cpp:717-720), 0 for a miss; march() forms the position from it.  (A float4 result set inside
+// the loop is four more registers that the loop's latch copies out and back on every round - the compiler threads the value of the
+// `return`s through the loop - where one will do: the position is three multiplications and three additions after the loop.)
 template <int Q, class V>
-__device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg, unsigned px, unsigned py,
-                                                 const M4 &view, float nearPlane, float farPlane, float step,
-                                                 float largestep, int &work) {
+__device__ __forceinline__ float cast_ray_group(const V &v, const SkipGrid &sg, unsigned px, unsigned py,
+                                                const M4 &view, float nearPlane, float farPlane, float step,
+                                                float largestep, int &work) {
     const int lane = threadIdx.x & 63;
     const int q = lane & (Q - 1), base = lane & ~(Q - 1);
     const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
@@ -397,10 +400,10 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
     const float smallest_tmax = fmin_h(fmin_h(tmax.x, tmax.y), fmin_h(tmax.x, tmax.z));
     const float tnear = fmax_h(largest_tmin, nearPlane);
     const float tfar = fmin_h(smallest_tmax, farPlane);
-    const float4 miss = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float miss = 0.f;
     if (!(tnear < tfar)) return miss;
 #if KFH_RAY_PROBES
-    if (sg.probe & 1) return make_float4(dir.x, dir.y, dir.z, 0.f);
+    if (sg.probe & 1) return miss;
 #endif
     const BrickRay br = sg.flags ? brick_ray(sg, origin, dir) : BrickRay{};
     float t = tnear, stepsize = largestep;
@@ -485,9 +488,7 @@ __device__ __forceinline__ float4 cast_ray_group(const V &v, const SkipGrid &sg,
         if (ekind == 1) return miss;                 // left the volume / far plane without a crossing
         if (ekind == 2) {                            // cpp:717-720
             if (lazy) f_t = interp(v, add3(origin, scale3(dir, t_ft)));
-            const float th = te + stepsize * fe / (f_t - fe);
-            const f3 p = add3(origin, scale3(dir, th));
-            return make_float4(p.x, p.y, p.z, th);
+            return te + stepsize * fe / (f_t - fe);
         }
         // cpp:713-715: first sample below 0.8 -> switch to the small step from here on
         small = true;
@@ -526,7 +527,12 @@ template <int Q, class V>
 __device__ __forceinline__ float4 march(const V &v, const SkipGrid &sg, unsigned x, unsigned y, const M4 &view,
                                         float nearPlane, float farPlane, float step, float largestep, int &work) {
     if (Q == 1) return cast_ray(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
-    return cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
+    const float th = cast_ray_group<Q>(v, sg, x, y, view, nearPlane, farPlane, step, largestep, work);
+    if (!(th > 0.f)) return make_float4(0.f, 0.f, 0.f, 0.f);      // (a hit's parameter is >= nearPlane > 0)
+    const f3 origin = mk3(view.m[0][3], view.m[1][3], view.m[2][3]);
+    const f3 dir = rotate(view, mk3((float)x, (float)y, 1.f));
+    const f3 p = add3(origin, scale3(dir, th));
+    return make_float4(p.x, p.y, p.z, th);
 }
 
 // raycastKernel (cpp:726-757)
