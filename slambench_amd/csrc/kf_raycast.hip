@@ -447,21 +447,20 @@ __device__ __forceinline__ float cast_ray_group(const V &v, const SkipGrid &sg, 
 #endif
             else f = interp(v, add3(origin, scale3(dir, tq)));
         }
-        // what the serial loop does at this sample: 0 continue, 1 out of range, 2 zero crossing, 3 large->small step
-        int kind = 0;
-        if (!in_range) kind = 1;
-        else if (!s_lazy && f < 0) kind = 2;
-        else if (!s_lazy && !small && f < 0.8f) kind = 3;
+        // what the serial loop does at this sample: 0 continue, 1 out of range, 2 zero crossing, 3 large->small step (as selects: the
+        // nested ifs compile to exec-mask branches on the scalar unit, in every round)
+        const bool sampled = in_range && !s_lazy;
+        int kind = (sampled && !small && f < 0.8f) ? 3 : 0;
+        kind = (sampled && f < 0) ? 2 : kind;
+        kind = in_range ? kind : 1;
+        if (first) {
+            // cpp:706-708: the march only starts if the sample at tnear (lane 0 of the first round) is positive; otherwise that
+            // lane reports "leave" and, being the group's first event, ends the ray as a miss
+            first = false;
+            if (q == 0 && sampled && !(f > 0)) kind = 1;
+        }
         const unsigned long long ball = __ballot(kind != 0);
         const unsigned evmask = (unsigned)((ball >> base) & ((1ull << Q) - 1ull));
-        if (first) {
-            // cpp:706-708: the march only starts if the sample at tnear (lane 0 of this round) is positive
-            first = false;
-            const float f0 = group_first<Q>(f, base);
-            const int lazy0 = group_first<Q>((int)s_lazy, base);
-            const int in0 = group_first<Q>((int)in_range, base);
-            if (in0 && !lazy0 && !(f0 > 0)) return miss;
-        }
         if (evmask == 0) {   // all Q samples are plain "continue": f_t <- last of them, t <- its time + stepsize
             // (Round 5 measured a look-ahead here - in free space every lane also examines the sample one round ahead, 2 Q samples per
             // round: bit-identical, 47.4 -> 51.0 us at cfg2, and 51.8 with the look-ahead switched off at run time: the loop does not
